@@ -1,0 +1,171 @@
+/*
+ * strotss_hip.h -- C ABI of libstrotss_hip.so: the MI355X (gfx950) kernels behind the
+ * STROTSS optimisation inner loop of interaction-lab-uh/STROTSS-tensorflow.
+ *
+ * The reference has NO native boundary: its hot path is a chain of TensorFlow op calls made
+ * from Python (run_strotss.py:131-148).  Each entry point below replaces the TF op(s) at the
+ * cited reference call site; the Python package strotss-tensorflow_amd/nn (same module and
+ * function names as the reference's nn/) binds them with ctypes (nn/_hip.py).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a CALLER-OWNED DEVICE pointer (float32 unless stated), never freed or
+ *     allocated by the library; workspaces are passed in explicitly;
+ *   - `stream` is the hipStream_t the work is enqueued on (as a void*); no call synchronises;
+ *   - return 0 on success, a negative STROTSS_E* for a bad argument (nothing is launched), or a
+ *     positive hipError_t from the launch;
+ *   - images / feature maps are NHWC with batch 1: (H, W, C) row-major, C contiguous;
+ *   - sampled feature matrices are (rows, ld) row-major with ld >= D, ld % 32 == 0, columns
+ *     [D, ld) and rows [n, rows) ZERO (the library keeps them zero); rows % 32 == 0;
+ *   - n-by-n cost matrices are (rows, ldc) row-major, ldc % 4 == 0.
+ */
+#ifndef STROTSS_HIP_H
+#define STROTSS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STROTSS_OK 0
+#define STROTSS_EINVAL (-1)   /* bad size / null pointer */
+#define STROTSS_EALIGN (-2)   /* leading dimension or K not a multiple of what the kernel needs */
+#define STROTSS_ERANGE (-3)   /* too many maps / tensors for the fixed-size descriptor */
+
+#define STROTSS_MAX_MAPS 12
+#define STROTSS_MAX_DIVS 8
+#define STROTSS_MAX_TENSORS 8
+
+/* library identity; also used by the loader to check the build. */
+int strotss_abi_version(void);
+const char* strotss_build_info(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Images: tf.image.resize(bilinear, half-pixel centres, no antialias)
+ *   replaces nn/utils.py:37,41 and nn/strotss_utils.py:142-143,162 (tf.image.resize)
+ * --------------------------------------------------------------------------------------- */
+/* out(oh,ow,c) = alpha*resize(in(ih,iw,c)) + (add ? add(oh,ow,c) : 0) ; alpha is +1 or -1 in
+ * practice: fold uses (add = residual, alpha = 1); make_laplacian uses (add = x, alpha = -1). */
+int strotss_resize_bilinear(const float* in, int ih, int iw, int c, float* out, int oh, int ow,
+                            float alpha, const float* add, void* stream);
+/* adjoint of the above w.r.t. `in`: gin(ih,iw,c) = resize^T(gout(oh,ow,c)).  Deterministic
+ * gather form (no atomics).  Replaces the TF gradient of strotss_utils.py:162. */
+int strotss_resize_bilinear_adjoint(const float* gout, int oh, int ow, int c, float* gin, int ih,
+                                    int iw, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * VGG16 trunk (frozen): nn/model.py:44-55 -- Keras Conv2D(3x3,'same',relu) / MaxPooling2D(2,2)
+ * --------------------------------------------------------------------------------------- */
+/* First layer with the ImageNet preprocess fused (model.py:50-51):
+ *   out(h,w,cout) = relu(conv3x3((img-mean)/std zero-padded, w_kio) + bias), img(h,w,3) in [0,1].
+ *   w_kio: (27, cout) = HWIO kernel flattened, k = (dy*3+dx)*3+ci.
+ *   mean3/std3 are the ONLY host pointers of this ABI: 3 floats each, the constants of
+ *   model.py:34-35, read at call time and passed to the kernel by value. */
+int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, const float* bias,
+                           int cout, const float* mean3, const float* std3, float* out, void* stream);
+/* Generic layer, cin % 32 == 0, cout % 64 == 0:
+ *   out(h,w,cout) = relu(conv3x3(in(h,w,cin)) + bias);  w_tok: (9, cout, cin), tap = dy*3+dx. */
+int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float* w_tok,
+                             const float* bias, int cout, float* out, void* stream);
+/* Data gradient of the generic layer (no weight gradient: the net is frozen, model.py:45):
+ *   gin(h,w,cin) = conv3x3^T(gout(h,w,cout)) [* (act_in > 0) if act_in != NULL]
+ *   gout must already carry the ReLU mask of ITS layer.  w_tik: (9, cin, cout) spatially
+ *   flipped kernel, tap' = (2-dy)*3+(2-dx).  act_in = the layer's (post-ReLU) input or NULL
+ *   when the input came from a max-pool. */
+int strotss_conv3x3_dgrad(const float* gout, int h, int w, int cout, const float* w_tik, int cin,
+                          const float* act_in, float* gin, void* stream);
+/* Data gradient of the first layer down to the pixels, preprocess adjoint fused:
+ *   gimg(h,w,3) (+)= conv3x3^T(gout(h,w,cout)) / std.   w_tic: (9, 3, cout) flipped kernel.
+ *   accumulate != 0 adds to gimg (the hypercolumn scatter of map 0 lands there first).
+ *   std3: HOST pointer, 3 floats. */
+int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const float* w_tic,
+                             const float* std3, float* gimg, int accumulate, void* stream);
+/* 2x2/2 VALID max-pool: out(h/2, w/2, c). */
+int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, void* stream);
+/* gin(h,w,c) = route gout(h/2,w/2,c) to the first max of each window, times (act > 0) where
+ * act(h,w,c) is the pooled layer's input (post-ReLU).  Overwrites gin. */
+int strotss_maxpool2_bwd(const float* act, int h, int w, int c, const float* gout, float* gin,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sampling._sample: hypercolumn gather  (nn/strotss_utils.py:25-81) and its adjoint
+ * --------------------------------------------------------------------------------------- */
+typedef struct {
+  int n_maps;
+  int h[STROTSS_MAX_MAPS], w[STROTSS_MAX_MAPS], c[STROTSS_MAX_MAPS];
+  int n_div[STROTSS_MAX_MAPS];                    /* how many entries of div[] apply to map k */
+  float div[STROTSS_MAX_DIVS];                    /* cumulative `indices /= y` chain (float32) */
+  const float* map[STROTSS_MAX_MAPS];             /* gather: sources; scatter: activations   */
+  float* gmap[STROTSS_MAX_MAPS];                  /* scatter only: gradient buffers           */
+} strotss_maps_t;
+/* out(rows, ld): row s < n = concat_k sample(map_k, idx[s]); bilinear != 0 -> 4-tap weights of
+ * strotss_utils.py:43-70, else truncating nearest (72-75).  idx: (n,2) float32 (row, col). */
+int strotss_hypercol_gather(const strotss_maps_t* maps, const float* idx, int n, int bilinear,
+                            float* out, int ld, void* stream);
+/* Adjoint (bilinear only): gmap_k[pixel, c] += w * gfeat[s, off_k + c] * (relu_mask ? map_k>0 : 1)
+ * for the maps k in [map_begin, map_end) only (the backward pass of the trunk needs the taps'
+ * contributions one layer at a time); gmap[k] may be NULL outside that range.
+ * relu_mask_from: maps with index >= relu_mask_from are post-ReLU activations (mask applied). */
+int strotss_hypercol_scatter(const strotss_maps_t* maps, const float* idx, int n,
+                             const float* gfeat, int ld, int relu_mask_from, int map_begin,
+                             int map_end, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Pairwise / moment losses  (nn/losses.py:12-80, run_strotss.py:21-40).
+ * Every loss entry computes the loss value AND d(loss)/d(pred) scaled by `gscale`, added
+ * into gpred (which the caller zero-fills once per step).  Scalars land in a device array.
+ * --------------------------------------------------------------------------------------- */
+/* r[i] = rsqrt(max(sum_k x[i,k]^2, 1e-12)) for i < n  (tf.nn.l2_normalize, losses.py:13-14) */
+int strotss_row_inv_norm(const float* x, int n, int ld, float* r, void* stream);
+/* C[i,j] = 1 - <x_i,y_j> * rx[i]*ry[j], i < nx, j < ny   (losses.py:12-15) */
+int strotss_cosine_distance(const float* x, const float* rx, int nx, const float* y,
+                            const float* ry, int ny, int ld, float* C, int ldc, void* stream);
+size_t strotss_selfsim_workspace_bytes(int n);
+/* loss_out[0] = self_similarity(pred, content) (losses.py:55-66);
+ * gpred += gscale * dloss/dpred.  pred/content: (rows >= n, ld). */
+int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int d, int ld,
+                            float gscale, float* gpred, float* loss_out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+size_t strotss_remd_workspace_bytes(int ns, int n);
+/* loss_out[0] = relaxed_emd(style, pred, 'cosine') (losses.py:69-80); gpred += gscale*dloss/dpred.
+ * rs = row_inv_norm(style) (constant per scale). */
+int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n,
+                             int d, int ld, float gscale, float* gpred, float* loss_out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* loss_out[0] = relaxed_emd(yuv(style[:, :3]), yuv(pred[:, :3]), 'both') (run_strotss.py:37-39);
+ * gpred[:, :3] += gscale*dloss/dpred[:, :3].  style/pred are the full (rows, ld) matrices. */
+int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld,
+                                 float gscale, float* gpred, float* loss_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+size_t strotss_moment_workspace_bytes(int n, int ld);
+/* style side of moment_matching, once per scale: mean_out(ld), cov_out(ld,ld) = biased covariance */
+int strotss_moment_stats(const float* x, int n, int d, int ld, float* mean_out, float* cov_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* loss_out[0] = moment_matching(style, pred) (losses.py:39-52) with the style statistics
+ * cached; gpred += gscale*dloss/dpred. */
+int strotss_moment_fwd_bwd(const float* style_mean, const float* style_cov, const float* pred,
+                           int n, int d, int ld, float gscale, float* gpred, float* loss_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser + output
+ * --------------------------------------------------------------------------------------- */
+typedef struct {
+  int n_tensors;
+  float* var[STROTSS_MAX_TENSORS];
+  float* rms[STROTSS_MAX_TENSORS];
+  const float* grad[STROTSS_MAX_TENSORS];
+  int64_t numel[STROTSS_MAX_TENSORS];
+} strotss_tensors_t;
+/* Keras RMSprop (momentum 0, not centred), run_strotss.py:63,148, all tensors in ONE launch:
+ *   rms = rho*rms + (1-rho)*g*g ;  var -= lr * g / (sqrt(rms) + eps) */
+int strotss_rmsprop_step(const strotss_tensors_t* t, float lr, float rho, float eps, void* stream);
+/* postprocess (strotss_utils.py:170-175): clip[0,1], -min, /max, *255, truncate to uint8.
+ * workspace: >= 2*1024 floats. */
+int strotss_postprocess(const float* img, int64_t numel, uint8_t* out, float* workspace,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STROTSS_HIP_H */

@@ -1,0 +1,154 @@
+// fp32-MFMA GEMMs of the loss path (cost matrices, covariance, their backward products).
+// All are C[m][n] = sum_k A(m,k) B(n,k) on the tile engine of mfma_tile.h with fused epilogues.
+#include "internal.h"
+#include "mfma_tile.h"
+
+namespace {
+
+template <int BM, int BN, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, int lda, int M,
+                                              const float* __restrict__ B, int ldb, int N, int K,
+                                              int m0, int n0, float* ldsA, float* ldsB,
+                                              f32x16 (&acc)[BM / 64][BN / 64]) {
+  f32x4 ra[BM / 32], rb[BN / 32];
+  auto load = [&](int k0) {
+    if constexpr (AKC) gload_kc<BM>(ra, A, lda, m0, M, k0); else gload_rc<BM>(ra, A, lda, m0, M, k0);
+    if constexpr (BKC) gload_kc<BN>(rb, B, ldb, n0, N, k0); else gload_rc<BN>(rb, B, ldb, n0, N, k0);
+  };
+  load(0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    __syncthreads();  // everyone is done reading the previous tile
+    if constexpr (AKC) lds_store_kc<BM>(ldsA, ra); else lds_store_rc<BM>(ldsA, ra);
+    if constexpr (BKC) lds_store_kc<BN>(ldsB, rb); else lds_store_rc<BN>(ldsB, rb);
+    __syncthreads();
+    if (k0 + 32 < K) load(k0 + 32);  // in flight under the MFMAs below
+    mma_kstep<BM, BN, AKC, BKC>(ldsA, ldsB, acc);
+  }
+}
+
+// ---------------------------------------------------------------- epilogues
+struct EpiCosDist {  // C = 1 - acc * (ra[i]*rb[j])      (losses.py:12-15)
+  const float* ra; const float* rb; float* C; int ldc; int M, N;
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    if (r < M && c < N) C[(size_t)r * ldc + c] = 1.0f - v * (ra[r] * rb[c]);
+    return 0.f;
+  }
+  __device__ __forceinline__ void finish(float*, float) const {}
+};
+struct EpiScaleStore {  // C = alpha * acc
+  float* C; int ldc; int M, N; float alpha;
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    if (r < M && c < N) C[(size_t)r * ldc + c] = alpha * v;
+    return 0.f;
+  }
+  __device__ __forceinline__ void finish(float*, float) const {}
+};
+struct EpiAxpbyBias {  // C = alpha*acc + C + bias[c]
+  float* C; int ldc; int M, N; float alpha; const float* bias; float bias_scale;
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    if (r < M && c < N) {
+      float* p = &C[(size_t)r * ldc + c];
+      *p = *p + alpha * v + bias_scale * bias[c];
+    }
+    return 0.f;
+  }
+  __device__ __forceinline__ void finish(float*, float) const {}
+};
+// moment_matching forward (losses.py:49-52): diff = acc/n - Sx; T = sign(diff); sum |diff|.
+struct EpiMomentFwd {
+  const float* Sx; float* T; int ld; int M, N; float inv_n; float* partial;
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    if (r < M && c < N) {
+      const size_t o = (size_t)r * ld + c;
+      const float diff = v * inv_n - Sx[o];
+      T[o] = signf(diff);
+      return fabsf(diff);
+    }
+    return 0.f;
+  }
+  __device__ __forceinline__ void finish(float* red, float local) const {
+    const float s = block_sum_256(local, red);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+};
+// self_similarity backward: dX[i,d] += g * r_i * (acc - xhat[i,d] * q_i), xhat = x * r_i
+struct EpiSelfsimBwd {
+  const float* x; const float* r; const float* q; float* dx; int ld; int M, N; float g;
+  __device__ __forceinline__ float apply(int row, int c, float v) const {
+    if (row < M && c < N) {
+      const size_t o = (size_t)row * ld + c;
+      const float ri = r[row];
+      dx[o] += g * ri * (v - x[o] * ri * q[row]);
+    }
+    return 0.f;
+  }
+  __device__ __forceinline__ void finish(float*, float) const {}
+};
+
+template <int BM, int BN, bool AKC, bool BKC, class Epi>
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, int M,
+                                                   const float* __restrict__ B, int ldb, int N, int K,
+                                                   Epi epi) {
+  __shared__ __attribute__((aligned(16))) float lds[OperandLds<BM>::floats + OperandLds<BN>::floats];
+  float* ldsA = lds;
+  float* ldsB = lds + OperandLds<BM>::floats;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  f32x16 acc[BM / 64][BN / 64];
+  acc_zero<BM, BN>(acc);
+  gemm_mainloop<BM, BN, AKC, BKC>(A, lda, M, B, ldb, N, K, m0, n0, ldsA, ldsB, acc);
+  AccMap<BM, BN> map;
+  float local = 0.f;
+#pragma unroll
+  for (int im = 0; im < BM / 64; ++im)
+#pragma unroll
+    for (int in = 0; in < BN / 64; ++in)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
+  epi.finish(lds, local);
+}
+
+template <int BM, int BN, bool AKC, bool BKC, class Epi>
+int launch(const float* A, int lda, int M, const float* B, int ldb, int N, int K, Epi epi,
+           hipStream_t s) {
+  dim3 grid(cdiv(N, BN), cdiv(M, BM));
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC, Epi>), grid, dim3(256), 0, s, A, lda, M, B, ldb, N,
+                     K, epi);
+  ST_LAUNCH_RET();
+}
+
+}  // namespace
+
+// C[i,j] = 1 - <x_i, y_j> rx[i] ry[j]
+int st_cosine_distance(const float* x, const float* rx, int nx, const float* y, const float* ry, int ny,
+                       int ld, float* C, int ldc, hipStream_t s) {
+  EpiCosDist e{rx, ry, C, ldc, nx, ny};
+  return launch<64, 64, true, true>(x, ld, nx, y, ld, ny, ld, e, s);
+}
+
+// C(M x N) = alpha * A^T A where A is (K x ld) row-major, rows [krows..) zero: covariance.
+int st_gram_tn(const float* A, int krows, int ld, float alpha, float* C, hipStream_t s) {
+  EpiScaleStore e{C, ld, ld, ld, alpha};
+  return launch<64, 64, false, false>(A, ld, ld, A, ld, ld, krows, e, s);
+}
+
+int st_moment_fwd_gemm(const float* cy, int krows, int ld, const float* Sx, float* T, float inv_n,
+                       float* partial, int* n_partial, hipStream_t s) {
+  EpiMomentFwd e{Sx, T, ld, ld, ld, inv_n, partial};
+  *n_partial = cdiv(ld, 64) * cdiv(ld, 64);
+  return launch<64, 64, false, false>(cy, ld, ld, cy, ld, ld, krows, e, s);
+}
+
+// dY(n x ld) += alpha * cy(n x ld) @ T(ld x ld, symmetric) + bias_scale * bias[c]
+int st_moment_bwd_gemm(const float* cy, int n, int ld, const float* T, float alpha, const float* bias,
+                       float bias_scale, float* dY, hipStream_t s) {
+  EpiAxpbyBias e{dY, ld, n, ld, alpha, bias, bias_scale};
+  return launch<64, 64, true, true>(cy, ld, n, T, ld, ld, ld, e, s);
+}
+
+// dX(n x ld) += g * r_i (Mq(n x kpad) @ X(kpad x ld) - xhat q)
+int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, const float* r, const float* q,
+                        int n, int ld, float g, float* dx, hipStream_t s) {
+  EpiSelfsimBwd e{x, r, q, dx, ld, n, ld, g};
+  return launch<64, 64, true, false>(Mq, ldm, n, x, ld, ld, kpad, e, s);
+}

@@ -1,0 +1,296 @@
+// HBM-bound image-side kernels of the STROTSS step: TF2 bilinear resize and its adjoint
+// (Laplacian fold, strotss_utils.py:139-163), hypercolumn gather / scatter-add
+// (Sampling._sample, strotss_utils.py:25-81), multi-tensor RMSprop (run_strotss.py:63,148),
+// postprocess (strotss_utils.py:170-175).
+#include "internal.h"
+
+namespace {
+
+// TF2 `tf.image.resize(bilinear)` source coordinate, computed in float32 exactly as TF's
+// HalfPixelScaler does: (float(i) + 0.5f) * scale - 0.5f   (no FMA contraction).
+struct AxisTap { int lo, hi; float lerp; };
+__device__ __forceinline__ AxisTap axis_tap(int i, float scale, int in_size) {
+  const float src = __fsub_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), scale), 0.5f);
+  const float fl = floorf(src);
+  AxisTap t;
+  t.lo = max((int)fl, 0);
+  t.hi = min((int)ceilf(src), in_size - 1);
+  t.lerp = __fsub_rn(src, fl);
+  return t;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, int ih, int iw,
+                                                              int c, float* __restrict__ out, int oh, int ow,
+                                                              float sy, float sx, float alpha,
+                                                              const float* __restrict__ add) {
+  const size_t total = (size_t)oh * ow * c;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int ch = (int)(e % c);
+    const size_t pix = e / c;
+    const int ox = (int)(pix % ow), oy = (int)(pix / ow);
+    const AxisTap ty = axis_tap(oy, sy, ih), tx = axis_tap(ox, sx, iw);
+    const float tl = in[((size_t)ty.lo * iw + tx.lo) * c + ch];
+    const float tr = in[((size_t)ty.lo * iw + tx.hi) * c + ch];
+    const float bl = in[((size_t)ty.hi * iw + tx.lo) * c + ch];
+    const float br = in[((size_t)ty.hi * iw + tx.hi) * c + ch];
+    const float top = tl + (tr - tl) * tx.lerp;
+    const float bot = bl + (br - bl) * tx.lerp;
+    float v = alpha * (top + (bot - top) * ty.lerp);
+    if (add) v += add[e];
+    out[e] = v;
+  }
+}
+
+// Adjoint as a gather: gin[iy,ix] = sum over the output pixels whose taps touch (iy,ix).
+__global__ __launch_bounds__(256) void resize_adjoint_kernel(const float* __restrict__ gout, int oh, int ow,
+                                                             int c, float* __restrict__ gin, int ih, int iw,
+                                                             float sy, float sx) {
+  const size_t total = (size_t)ih * iw * c;
+  const float isy = 1.0f / sy, isx = 1.0f / sx;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int ch = (int)(e % c);
+    const size_t pix = e / c;
+    const int ix = (int)(pix % iw), iy = (int)(pix / iw);
+    // candidates: src(o) in (i-1, i+1)  <=>  o in ((i-0.5)/s - 0.5, (i+1.5)/s - 0.5); +-1 safety margin
+    const int oy0 = max(0, (int)floorf(((float)iy - 0.5f) * isy - 0.5f) - 1);
+    const int oy1 = min(oh - 1, (int)ceilf(((float)iy + 1.5f) * isy - 0.5f) + 1);
+    const int ox0 = max(0, (int)floorf(((float)ix - 0.5f) * isx - 0.5f) - 1);
+    const int ox1 = min(ow - 1, (int)ceilf(((float)ix + 1.5f) * isx - 0.5f) + 1);
+    float acc = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      const AxisTap ty = axis_tap(oy, sy, ih);
+      const float wy = (ty.lo == iy ? 1.0f - ty.lerp : 0.f) + (ty.hi == iy ? ty.lerp : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        const AxisTap tx = axis_tap(ox, sx, iw);
+        const float wx = (tx.lo == ix ? 1.0f - tx.lerp : 0.f) + (tx.hi == ix ? tx.lerp : 0.f);
+        if (wx != 0.f) row += wx * gout[((size_t)oy * ow + ox) * c + ch];
+      }
+      acc += wy * row;
+    }
+    gin[e] = acc;
+  }
+}
+
+// ---------------------------------------------------------------- hypercolumns
+struct SampleTap { int ia, ib, ic, id; float wa, wb, wc, wd; };
+
+// strotss_utils.py:31-37 (cumulative float32 `indices /= y`) + 43-64 (floor / clip / 4 taps)
+__device__ __forceinline__ SampleTap sample_tap(const strotss_maps_t& m, int k, float gx, float gy,
+                                                int bilinear) {
+  for (int q = 0; q < m.n_div[k]; ++q) {
+    gx = __fdiv_rn(gx, m.div[q]);
+    gy = __fdiv_rn(gy, m.div[q]);
+  }
+  const int h = m.h[k], w = m.w[k];
+  SampleTap t;
+  if (bilinear) {
+    const float gxf = floorf(gx), gyf = floorf(gy);
+    const float dx = gx - gxf, dy = gy - gyf;
+    t.wa = (1.f - dx) * (1.f - dy);
+    t.wb = (1.f - dx) * dy;
+    t.wc = dx * (1.f - dy);
+    t.wd = dx * dy;
+    const int x0 = (int)fminf(fmaxf(gxf, 0.f), (float)(h - 1));
+    const int y0 = (int)fminf(fmaxf(gyf, 0.f), (float)(w - 1));
+    const int x1 = min(x0 + 1, h - 1), y1 = min(y0 + 1, w - 1);
+    t.ia = x0 * w + y0; t.ib = x0 * w + y1; t.ic = x1 * w + y0; t.id = x1 * w + y1;
+  } else {
+    const int xi = (int)fminf(fmaxf(gx, 0.f), (float)(h - 1));   // clip, then truncating cast
+    const int yi = (int)fminf(fmaxf(gy, 0.f), (float)(w - 1));
+    t.ia = t.ib = t.ic = t.id = xi * w + yi;
+    t.wa = 1.f; t.wb = t.wc = t.wd = 0.f;
+  }
+  return t;
+}
+
+// one block per sample row
+__global__ __launch_bounds__(256) void hypercol_gather_kernel(strotss_maps_t m, const float* __restrict__ idx,
+                                                              int bilinear, float* __restrict__ out, int ld,
+                                                              int dtotal) {
+  const int s = blockIdx.x;
+  const float gx = idx[2 * s], gy = idx[2 * s + 1];
+  float* o = out + (size_t)s * ld;
+  int off = 0;
+  for (int k = 0; k < m.n_maps; ++k) {
+    const SampleTap t = sample_tap(m, k, gx, gy, bilinear);
+    const int c = m.c[k];
+    const float* src = m.map[k];
+    if (bilinear) {
+      const float* pa = src + (size_t)t.ia * c; const float* pb = src + (size_t)t.ib * c;
+      const float* pc = src + (size_t)t.ic * c; const float* pd = src + (size_t)t.id * c;
+      for (int ch = threadIdx.x; ch < c; ch += 256)
+        o[off + ch] = pa[ch] * t.wa + pb[ch] * t.wb + pc[ch] * t.wc + pd[ch] * t.wd;
+    } else {
+      const float* pa = src + (size_t)t.ia * c;
+      for (int ch = threadIdx.x; ch < c; ch += 256) o[off + ch] = pa[ch];
+    }
+    off += c;
+  }
+  for (int ch = dtotal + threadIdx.x; ch < ld; ch += 256) o[ch] = 0.f;
+}
+
+// adjoint of the bilinear gather: float atomics, 256 contiguous bytes per wave instruction
+__global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m, const float* __restrict__ idx,
+                                                               const float* __restrict__ gfeat, int ld,
+                                                               int relu_mask_from, int map_begin,
+                                                               int map_end) {
+  const int s = blockIdx.x;
+  const float gx = idx[2 * s], gy = idx[2 * s + 1];
+  const float* g = gfeat + (size_t)s * ld;
+  int off = 0;
+  for (int k = 0; k < map_end; ++k) {
+    const int c = m.c[k];
+    if (k < map_begin) { off += c; continue; }
+    const SampleTap t = sample_tap(m, k, gx, gy, 1);
+    const float* act = m.map[k];
+    float* dst = m.gmap[k];
+    const bool masked = k >= relu_mask_from;
+    const int ii[4] = {t.ia, t.ib, t.ic, t.id};
+    const float ww[4] = {t.wa, t.wb, t.wc, t.wd};
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      const float gv = g[off + ch];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (ww[q] == 0.f) continue;
+        const size_t o = (size_t)ii[q] * c + ch;
+        if (masked && !(act[o] > 0.f)) continue;
+        atomicAdd(&dst[o], ww[q] * gv);
+      }
+    }
+    off += c;
+  }
+}
+
+// ---------------------------------------------------------------- optimiser
+__global__ __launch_bounds__(256) void rmsprop_kernel(strotss_tensors_t t, float lr, float rho, float eps) {
+  const int k = blockIdx.y;
+  float* var = t.var[k];
+  float* rms = t.rms[k];
+  const float* g = t.grad[k];
+  const int64_t n = t.numel[k];
+  const float omr = 1.0f - rho;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float gv = g[e];
+    const float r = rho * rms[e] + omr * (gv * gv);
+    rms[e] = r;
+    var[e] = var[e] - lr * gv / (sqrtf(r) + eps);
+  }
+}
+
+// ---------------------------------------------------------------- postprocess
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, int64_t n,
+                                                             float* __restrict__ ws) {
+  __shared__ float red[4];
+  float mn = INFINITY, mx = -INFINITY;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float v = fminf(fmaxf(x[e], 0.f), 1.f);
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  mn = block_min_256(mn, red);
+  mx = block_max_256(mx, red);
+  if (threadIdx.x == 0) { ws[blockIdx.x] = mn; ws[1024 + blockIdx.x] = mx; }
+}
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ x, int64_t n,
+                                                          const float* __restrict__ ws, int nparts,
+                                                          uint8_t* __restrict__ out) {
+  __shared__ float red[4];
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < nparts; i += 256) { mn = fminf(mn, ws[i]); mx = fmaxf(mx, ws[1024 + i]); }
+  mn = block_min_256(mn, red);
+  mx = block_max_256(mx, red);
+  const float range = mx - mn;   // == max(x - min) : float subtraction is monotone
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    float v = fminf(fmaxf(x[e], 0.f), 1.f);
+    v = (v - mn) / range;
+    out[e] = (uint8_t)(v * 255.0f);   // truncating cast, as tf.cast(float -> uint8)
+  }
+}
+
+int maps_ok(const strotss_maps_t* m) {
+  if (!m || m->n_maps <= 0 || m->n_maps > STROTSS_MAX_MAPS) return 0;
+  for (int k = 0; k < m->n_maps; ++k) {
+    if (m->h[k] <= 0 || m->w[k] <= 0 || m->c[k] <= 0 || !m->map[k]) return 0;
+    if (m->n_div[k] < 0 || m->n_div[k] > STROTSS_MAX_DIVS) return 0;
+  }
+  return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int strotss_abi_version(void) { return 1; }
+const char* strotss_build_info(void) { return "libstrotss_hip gfx950 fp32-mfma " __DATE__ " " __TIME__; }
+
+int strotss_resize_bilinear(const float* in, int ih, int iw, int c, float* out, int oh, int ow, float alpha,
+                            const float* add, void* stream) {
+  ST_CHECK_ARG(in && out && ih > 0 && iw > 0 && oh > 0 && ow > 0 && c > 0, STROTSS_EINVAL);
+  const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;   // CalculateResizeScale
+  const size_t total = (size_t)oh * ow * c;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, ih, iw, c, out, oh, ow, sy, sx, alpha, add);
+  ST_LAUNCH_RET();
+}
+
+int strotss_resize_bilinear_adjoint(const float* gout, int oh, int ow, int c, float* gin, int ih, int iw,
+                                    void* stream) {
+  ST_CHECK_ARG(gout && gin && ih > 0 && iw > 0 && oh > 0 && ow > 0 && c > 0, STROTSS_EINVAL);
+  const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+  const size_t total = (size_t)ih * iw * c;
+  hipLaunchKernelGGL(resize_adjoint_kernel, dim3(min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, gout, oh, ow, c, gin, ih, iw, sy, sx);
+  ST_LAUNCH_RET();
+}
+
+int strotss_hypercol_gather(const strotss_maps_t* maps, const float* idx, int n, int bilinear, float* out,
+                            int ld, void* stream) {
+  ST_CHECK_ARG(maps_ok(maps) && idx && out && n > 0, STROTSS_EINVAL);
+  int d = 0;
+  for (int k = 0; k < maps->n_maps; ++k) d += maps->c[k];
+  ST_CHECK_ARG(ld >= d, STROTSS_EINVAL);
+  hipLaunchKernelGGL(hypercol_gather_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, *maps, idx, bilinear,
+                     out, ld, d);
+  ST_LAUNCH_RET();
+}
+
+int strotss_hypercol_scatter(const strotss_maps_t* maps, const float* idx, int n, const float* gfeat, int ld,
+                             int relu_mask_from, int map_begin, int map_end, void* stream) {
+  ST_CHECK_ARG(maps_ok(maps) && idx && gfeat && n > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(map_begin >= 0 && map_begin < map_end && map_end <= maps->n_maps, STROTSS_ERANGE);
+  int d = 0;
+  for (int k = 0; k < maps->n_maps; ++k) {
+    if (k >= map_begin && k < map_end) ST_CHECK_ARG(maps->gmap[k] != nullptr, STROTSS_EINVAL);
+    d += maps->c[k];
+  }
+  ST_CHECK_ARG(ld >= d, STROTSS_EINVAL);
+  hipLaunchKernelGGL(hypercol_scatter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, *maps, idx, gfeat,
+                     ld, relu_mask_from, map_begin, map_end);
+  ST_LAUNCH_RET();
+}
+
+int strotss_rmsprop_step(const strotss_tensors_t* t, float lr, float rho, float eps, void* stream) {
+  ST_CHECK_ARG(t && t->n_tensors > 0 && t->n_tensors <= STROTSS_MAX_TENSORS, STROTSS_ERANGE);
+  int64_t mx = 0;
+  for (int k = 0; k < t->n_tensors; ++k) {
+    ST_CHECK_ARG(t->var[k] && t->rms[k] && t->grad[k] && t->numel[k] > 0, STROTSS_EINVAL);
+    mx = t->numel[k] > mx ? t->numel[k] : mx;
+  }
+  dim3 grid((unsigned)((mx + 255) / 256 > 2048 ? 2048 : (mx + 255) / 256), t->n_tensors);
+  hipLaunchKernelGGL(rmsprop_kernel, grid, dim3(256), 0, (hipStream_t)stream, *t, lr, rho, eps);
+  ST_LAUNCH_RET();
+}
+
+int strotss_postprocess(const float* img, int64_t numel, uint8_t* out, float* workspace, void* stream) {
+  ST_CHECK_ARG(img && out && workspace && numel > 0, STROTSS_EINVAL);
+  const int nparts = (int)((numel + 255) / 256 > 1024 ? 1024 : (numel + 255) / 256);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, img, numel,
+                     workspace);
+  hipLaunchKernelGGL(postprocess_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, img, numel,
+                     workspace, nparts, out);
+  ST_LAUNCH_RET();
+}
+
+}  // extern "C"

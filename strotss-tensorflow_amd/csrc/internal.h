@@ -1,0 +1,33 @@
+// Internal (non-ABI) launchers shared between the translation units of libstrotss_hip.so.
+#pragma once
+#include "common.h"
+
+// gemm.hip
+int st_cosine_distance(const float* x, const float* rx, int nx, const float* y, const float* ry, int ny,
+                       int ld, float* C, int ldc, hipStream_t s);
+int st_gram_tn(const float* A, int krows, int ld, float alpha, float* C, hipStream_t s);
+int st_moment_fwd_gemm(const float* cy, int krows, int ld, const float* Sx, float* T, float inv_n,
+                       float* partial, int* n_partial, hipStream_t s);
+int st_moment_bwd_gemm(const float* cy, int n, int ld, const float* T, float alpha, const float* bias,
+                       float bias_scale, float* dY, hipStream_t s);
+int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, const float* r, const float* q,
+                        int n, int ld, float g, float* dx, hipStream_t s);
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Bump allocator over a caller-provided workspace (256-byte aligned slices).
+struct Workspace {
+  char* base; size_t size; size_t off;
+  Workspace(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+  template <class T> T* take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (off + bytes > size) { failed = true; return nullptr; }
+    T* r = reinterpret_cast<T*>(base + off);  // base == nullptr: planning pass, never dereferenced
+    off += bytes;
+    return r;
+  }
+  bool failed = false;
+  bool ok() const { return !failed; }
+  static Workspace planner() { return Workspace(nullptr, (size_t)1 << 60); }
+};
+static inline size_t ws_slice(size_t count, size_t elt) { return (count * elt + 255) & ~(size_t)255; }

@@ -1,0 +1,546 @@
+// Loss path of the STROTSS step (nn/losses.py:12-80, run_strotss.py:21-40): reductions and
+// sparse backward passes around the MFMA cost-matrix GEMMs of gemm.hip.  Every reduction
+// uses a fixed tree, so results are bitwise reproducible run to run.
+#include "internal.h"
+
+namespace {
+
+// r[i] = 1/sqrt(max(sum x^2, 1e-12))                 tf.nn.l2_normalize (losses.py:13-14)
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ x, int n, int ld,
+                                                           float* __restrict__ r) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* p = x + (size_t)row * ld;
+  float s = 0.f;
+  for (int k = lane * 4; k < ld; k += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + k);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  s = wave_sum(s);
+  if (lane == 0) r[row] = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+}
+
+// s[i] = sum_{j<n} D[i,j]
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ D, int n, int ldc,
+                                                      float* __restrict__ s) {
+  __shared__ float red[4];
+  const float* p = D + (size_t)blockIdx.x * ldc;
+  float a = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) a += p[j];
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) s[blockIdx.x] = a;
+}
+
+// self_similarity (losses.py:55-66) on the TRANSPOSED matrices: the cosine matrices are bitwise
+// symmetric (gemm.hip), so column j of D / colsum[j] == row j of D / rowsum[j].
+// Row j:  A' = Dx[j,:]/sx_j, B' = Dy[j,:]/sy_j, loss_j = sum |A'-B'|, S' = sign(A'-B') * sscale,
+//         t_j = sum S' A' (0 when the clamp is active), Q[j,:] = (S' - t_j)/sx_j  (= dL/dDx[:,j]).
+__global__ __launch_bounds__(256) void selfsim_rowpass_kernel(const float* __restrict__ Dx,
+                                                              const float* __restrict__ Dy,
+                                                              const float* __restrict__ sx_raw,
+                                                              const float* __restrict__ sy_raw, int n,
+                                                              int ldc, float sscale, float* __restrict__ Q,
+                                                              float* __restrict__ lossrow) {
+  __shared__ float red[4];
+  const int j = blockIdx.x;
+  const float sxr = sx_raw[j], syr = sy_raw[j];
+  const float isx = 1.0f / fmaxf(sxr, 1e-12f), isy = 1.0f / fmaxf(syr, 1e-12f);
+  const float* px = Dx + (size_t)j * ldc;
+  const float* py = Dy + (size_t)j * ldc;
+  float l = 0.f, t = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float a = px[i] * isx, b = py[i] * isy;
+    const float d = a - b;
+    l += fabsf(d);
+    t += signf(d) * sscale * a;
+  }
+  l = block_sum_256(l, red);
+  t = block_sum_256(t, red);
+  if (!(sxr >= 1e-12f)) t = 0.f;
+  float* q = Q + (size_t)j * ldc;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float a = px[i] * isx, b = py[i] * isy;
+    q[i] = (signf(a - b) * sscale - t) * isx;
+  }
+  if (threadIdx.x == 0) lossrow[j] = l;
+}
+
+// M[i,j] = -(Q[i,j] + Q[j,i]);  Mq[i,j] = M[i,j] * r[j] (zero for n <= j < kpad);
+// qdot[i] = sum_j M[i,j] (1 - Dx[i,j])   (= xhat_i . dL/dxhat_i)
+__global__ __launch_bounds__(256) void selfsim_sym_kernel(const float* __restrict__ Q,
+                                                          const float* __restrict__ Dx,
+                                                          const float* __restrict__ r, int n, int ldc,
+                                                          int kpad, float* __restrict__ Mq,
+                                                          float* __restrict__ qdot) {
+  __shared__ float red[4];
+  const int i = blockIdx.x;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < kpad; j += 256) {
+    float out = 0.f;
+    if (j < n) {
+      const float m = -(Q[(size_t)i * ldc + j] + Q[(size_t)j * ldc + i]);
+      acc += m * (1.0f - Dx[(size_t)i * ldc + j]);
+      out = m * r[j];
+    }
+    Mq[(size_t)i * ldc + j] = out;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) qdot[i] = acc;
+}
+
+// out[0] = scale * sum(partial[0..count))      (single block, fixed order)
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ partial, int count,
+                                                         float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < count; i += 256) a += partial[i];
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) out[0] = a * scale;
+}
+
+// ---------------------------------------------------------------- relaxed EMD
+// rmin[i] = min_j C[i,j], rcnt[i] = #{j : C[i,j] == rmin[i]}
+__global__ __launch_bounds__(256) void row_min_kernel(const float* __restrict__ C, int n, int ldc,
+                                                      float* __restrict__ rmin, float* __restrict__ rcnt) {
+  __shared__ float red[4];
+  const float* p = C + (size_t)blockIdx.x * ldc;
+  float m = INFINITY;
+  for (int j = threadIdx.x; j < n; j += 256) m = fminf(m, p[j]);
+  m = block_min_256(m, red);
+  float c = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) c += (p[j] == m) ? 1.f : 0.f;
+  c = block_sum_256(c, red);
+  if (threadIdx.x == 0) { rmin[blockIdx.x] = m; rcnt[blockIdx.x] = c; }
+}
+// cmin[j] = min_i C[i,j], ccnt[j] = #{i : C[i,j] == cmin[j]};  64 columns per block
+__global__ __launch_bounds__(256) void col_min_kernel(const float* __restrict__ C, int ns, int n, int ldc,
+                                                      float* __restrict__ cmin, float* __restrict__ ccnt) {
+  __shared__ float sm[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  float m = INFINITY;
+  if (j < n)
+    for (int i = g; i < ns; i += 4) m = fminf(m, C[(size_t)i * ldc + j]);
+  sm[g][c] = m;
+  __syncthreads();
+  m = fminf(fminf(sm[0][c], sm[1][c]), fminf(sm[2][c], sm[3][c]));
+  __syncthreads();
+  float cnt = 0.f;
+  if (j < n)
+    for (int i = g; i < ns; i += 4) cnt += (C[(size_t)i * ldc + j] == m) ? 1.f : 0.f;
+  sm[g][c] = cnt;
+  __syncthreads();
+  if (g == 0 && j < n) {
+    cmin[j] = m;
+    ccnt[j] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+  }
+}
+// loss = max(mean rmin, mean cmin); sel[0] = 1 when the row branch carries the gradient
+// (tf.maximum: first argument on ties).
+__global__ __launch_bounds__(256) void remd_select_kernel(const float* __restrict__ rmin, int ns,
+                                                          const float* __restrict__ cmin, int n,
+                                                          float* __restrict__ loss_out, int* __restrict__ sel) {
+  __shared__ float red[4];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < ns; i += 256) a += rmin[i];
+  for (int i = threadIdx.x; i < n; i += 256) b += cmin[i];
+  a = block_sum_256(a, red);
+  b = block_sum_256(b, red);
+  if (threadIdx.x == 0) {
+    const float rx = a / (float)ns, ry = b / (float)n;
+    const int s = rx >= ry;
+    loss_out[0] = s ? rx : ry;
+    sel[0] = s;
+  }
+}
+
+#define REMD_MAX_LIST 2048
+// One block per pred sample j.  Builds the (ordered) list of style rows whose cost entry
+// carries gradient for column j, then dY_j += g * ry_j (ghat - yhat (yhat.ghat)), ghat = -sum w xhat_i.
+__global__ __launch_bounds__(256) void remd_cos_bwd_kernel(
+    const float* __restrict__ C, int ldc, const float* __restrict__ style, const float* __restrict__ rs,
+    int ns, const float* __restrict__ pred, const float* __restrict__ rp, int n, int ld,
+    const float* __restrict__ rmin, const float* __restrict__ rcnt, const float* __restrict__ cmin,
+    const float* __restrict__ ccnt, const int* __restrict__ sel, float gscale, float* __restrict__ gpred) {
+  __shared__ int li[REMD_MAX_LIST];
+  __shared__ float lw[REMD_MAX_LIST];
+  __shared__ int cnts[256];
+  __shared__ float red[4];
+  const int j = blockIdx.x, t = threadIdx.x;
+  const int row_branch = sel[0];
+  const int per = (ns + 255) / 256;
+  const int i0 = t * per, i1 = min(ns, i0 + per);
+  const float cm = cmin[j], cc = ccnt[j];
+  int c = 0;
+  for (int i = i0; i < i1; ++i) {
+    const float v = C[(size_t)i * ldc + j];
+    c += row_branch ? (v == rmin[i]) : (v == cm);
+  }
+  cnts[t] = c;
+  __syncthreads();
+  int off = 0, total = 0;
+  for (int k = 0; k < 256; ++k) {
+    const int ck = cnts[k];
+    off += (k < t) ? ck : 0;
+    total += ck;
+  }
+  float qpart = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const float v = C[(size_t)i * ldc + j];
+    const bool hit = row_branch ? (v == rmin[i]) : (v == cm);
+    if (hit) {
+      const float w = row_branch ? 1.0f / ((float)ns * rcnt[i]) : 1.0f / ((float)n * cc);
+      if (off < REMD_MAX_LIST) { li[off] = i; lw[off] = w * rs[i]; }
+      qpart += w * (1.0f - v);
+      ++off;
+    }
+  }
+  const float q = -block_sum_256(qpart, red);  // yhat_j . ghat_j   (also syncs li/lw)
+  total = min(total, REMD_MAX_LIST);
+  if (total == 0) return;
+  const float rj = rp[j];
+  const float live = (rj < 1.0f / sqrtf(1e-12f)) ? 1.f : 0.f;
+  const float* y = pred + (size_t)j * ld;
+  float* gy = gpred + (size_t)j * ld;
+  for (int k = t; k < ld; k += 256) {
+    float acc = 0.f;
+    for (int e = 0; e < total; ++e) acc += lw[e] * style[(size_t)li[e] * ld + k];
+    gy[k] += gscale * rj * (-acc - y[k] * rj * q * live);
+  }
+}
+
+// ---------------------------------------------------------------- palette (D = 3, pure VALU)
+// yuv[i] = (Y, U, V, r) with r the inverse norm of the YUV vector  (strotss_utils.py:166-167)
+__global__ __launch_bounds__(256) void palette_prepare_kernel(const float* __restrict__ feat, int n, int ld,
+                                                              f32x4* __restrict__ yuv) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* p = feat + (size_t)i * ld;
+  const float R = p[0], G = p[1], B = p[2];
+  const float Y = R * 0.299f + G * 0.587f + B * 0.114f;
+  const float U = R * -0.14714119f + G * -0.28886916f + B * 0.43601035f;
+  const float V = R * 0.61497538f + G * -0.51496512f + B * -0.10001026f;
+  const float ss = Y * Y + U * U + V * V;
+  f32x4 o = {Y, U, V, 1.0f / sqrtf(fmaxf(ss, 1e-12f))};
+  yuv[i] = o;
+}
+__device__ __forceinline__ void palette_pair(const f32x4 a, const f32x4 b, float& ccos, float& m) {
+  const float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  ccos = 1.0f - dot * (a[3] * b[3]);
+  const float xs = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+  const float ys = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+  m = xs + ys - 2.0f * dot;                        // losses.py:22
+}
+// C[i,j] = cosine + sqrt(max(m,1e-6)/3)           dist_metrics['both'] (losses.py:27-28)
+__global__ __launch_bounds__(256) void palette_cost_kernel(const f32x4* __restrict__ ys, int ns,
+                                                           const f32x4* __restrict__ yp, int n,
+                                                           float* __restrict__ C, int ldc) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= n) return;
+  float cc, m;
+  palette_pair(ys[i], yp[j], cc, m);
+  C[(size_t)i * ldc + j] = cc + sqrtf(fmaxf(m, 1e-6f) / 3.0f);
+}
+// One wave per pred sample j.
+__global__ __launch_bounds__(64) void palette_bwd_kernel(
+    const float* __restrict__ C, int ldc, const f32x4* __restrict__ ys, int ns, const f32x4* __restrict__ yp,
+    int n, const float* __restrict__ rmin, const float* __restrict__ rcnt, const float* __restrict__ cmin,
+    const float* __restrict__ ccnt, const int* __restrict__ sel, float gscale, float* __restrict__ gpred,
+    int ld) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  const int row_branch = sel[0];
+  const f32x4 y = yp[j];
+  const float cm = cmin[j], cc = ccnt[j];
+  float gh0 = 0.f, gh1 = 0.f, gh2 = 0.f, q = 0.f, sk = 0.f, kx0 = 0.f, kx1 = 0.f, kx2 = 0.f;
+  for (int i = lane; i < ns; i += 64) {
+    const float v = C[(size_t)i * ldc + j];
+    const bool hit = row_branch ? (v == rmin[i]) : (v == cm);
+    if (hit) {
+      const float w = row_branch ? 1.0f / ((float)ns * rcnt[i]) : 1.0f / ((float)n * cc);
+      const f32x4 x = ys[i];
+      float ccos, m;
+      palette_pair(x, y, ccos, m);
+      const float wr = w * x[3];
+      gh0 -= wr * x[0]; gh1 -= wr * x[1]; gh2 -= wr * x[2];
+      q -= w * (1.0f - ccos);
+      if (m >= 1e-6f) {
+        const float k = w / (3.0f * sqrtf(m / 3.0f));
+        sk += k; kx0 += k * x[0]; kx1 += k * x[1]; kx2 += k * x[2];
+      }
+    }
+  }
+  gh0 = wave_sum(gh0); gh1 = wave_sum(gh1); gh2 = wave_sum(gh2); q = wave_sum(q);
+  sk = wave_sum(sk); kx0 = wave_sum(kx0); kx1 = wave_sum(kx1); kx2 = wave_sum(kx2);
+  if (lane == 0) {
+    const float rj = y[3];
+    const float live = (rj < 1.0f / sqrtf(1e-12f)) ? 1.f : 0.f;
+    const float d0 = rj * (gh0 - y[0] * rj * q * live) + sk * y[0] - kx0;
+    const float d1 = rj * (gh1 - y[1] * rj * q * live) + sk * y[1] - kx1;
+    const float d2 = rj * (gh2 - y[2] * rj * q * live) + sk * y[2] - kx2;
+    // back through yuv = rgb @ M :  d_rgb = d_yuv @ M^T
+    float* g = gpred + (size_t)j * ld;
+    g[0] += gscale * (d0 * 0.299f + d1 * -0.14714119f + d2 * 0.61497538f);
+    g[1] += gscale * (d0 * 0.587f + d1 * -0.28886916f + d2 * -0.51496512f);
+    g[2] += gscale * (d0 * 0.114f + d1 * 0.43601035f + d2 * -0.10001026f);
+  }
+}
+
+// ---------------------------------------------------------------- moment matching helpers
+// mean[c] = (1/n) sum_{i<n} y[i,c];  64 columns per block
+__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ y, int n, int ld,
+                                                       float* __restrict__ mean) {
+  __shared__ float sm[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  float a = 0.f;
+  if (col < ld)
+    for (int i = g; i < n; i += 4) a += y[(size_t)i * ld + col];
+  sm[g][c] = a;
+  __syncthreads();
+  if (g == 0 && col < ld) mean[col] = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) / (float)n;
+}
+// cy[i,c] = y[i,c] - mean[c] for i < n, 0 for n <= i < rows
+__global__ __launch_bounds__(256) void center_kernel(const float* __restrict__ y, int n, int rows, int ld,
+                                                     const float* __restrict__ mean, float* __restrict__ cy) {
+  const size_t total4 = (size_t)rows * ld / 4;
+  const int ld4 = ld / 4;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
+    const int i = (int)(e / ld4), c4 = (int)(e % ld4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+      v = reinterpret_cast<const f32x4*>(y)[e];
+      const f32x4 m = reinterpret_cast<const f32x4*>(mean)[c4];
+      v = v - m;
+    }
+    reinterpret_cast<f32x4*>(cy)[e] = v;
+  }
+}
+// loss = sum(partial)/d^2 + sum_c |mx-my|/d ;  sgn[c] = sign(my - mx)
+__global__ __launch_bounds__(256) void moment_finalize_kernel(const float* __restrict__ partial, int count,
+                                                              const float* __restrict__ mx,
+                                                              const float* __restrict__ my, int d, int ld,
+                                                              float* __restrict__ sgn,
+                                                              float* __restrict__ loss_out) {
+  __shared__ float red[4];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < count; i += 256) a += partial[i];
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    const float df = (c < d) ? (my[c] - mx[c]) : 0.f;
+    b += fabsf(df);
+    sgn[c] = signf(df);
+  }
+  a = block_sum_256(a, red);
+  b = block_sum_256(b, red);
+  if (threadIdx.x == 0) loss_out[0] = a / ((float)d * (float)d) + b / (float)d;
+}
+
+#define CHK(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+#define LAUNCH_OK()                                  \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+bool feat_ok(int n, int d, int ld) { return n > 0 && d > 0 && ld >= d; }
+
+struct SelfsimWs {
+  float *rp, *rc, *Dx, *Dy, *sx, *sy, *Q, *Mq, *qdot, *lossrow;
+  int ldc;
+  bool plan(Workspace& w, int n) {
+    ldc = round_up(n, 32);
+    rp = w.take<float>(ldc); rc = w.take<float>(ldc);
+    Dx = w.take<float>((size_t)n * ldc); Dy = w.take<float>((size_t)n * ldc);
+    sx = w.take<float>(ldc); sy = w.take<float>(ldc);
+    Q = w.take<float>((size_t)n * ldc); Mq = w.take<float>((size_t)n * ldc);
+    qdot = w.take<float>(ldc); lossrow = w.take<float>(ldc);
+    return w.ok();
+  }
+};
+struct RemdWs {
+  float *rp, *C, *rmin, *rcnt, *cmin, *ccnt;
+  f32x4 *ys, *yp;
+  int* sel;
+  int ldc;
+  bool plan(Workspace& w, int ns, int n) {
+    ldc = round_up(n, 32);
+    rp = w.take<float>(ldc);
+    C = w.take<float>((size_t)ns * ldc);
+    rmin = w.take<float>(ns); rcnt = w.take<float>(ns);
+    cmin = w.take<float>(ldc); ccnt = w.take<float>(ldc);
+    ys = w.take<f32x4>(ns); yp = w.take<f32x4>(n);
+    sel = w.take<int>(4);
+    return w.ok();
+  }
+};
+struct MomentWs {
+  float *mean, *cy, *T, *partial, *sgn;
+  int rows;
+  bool plan(Workspace& w, int n, int ld) {
+    rows = round_up(n, 32);
+    mean = w.take<float>(ld);
+    cy = w.take<float>((size_t)rows * ld);
+    T = w.take<float>((size_t)ld * ld);
+    partial = w.take<float>((size_t)cdiv(ld, 64) * cdiv(ld, 64));
+    sgn = w.take<float>(ld);
+    return w.ok();
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int strotss_row_inv_norm(const float* x, int n, int ld, float* r, void* stream) {
+  ST_CHECK_ARG(x && r && n > 0 && ld > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 4 == 0, STROTSS_EALIGN);
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, n, ld, r);
+  ST_LAUNCH_RET();
+}
+
+int strotss_cosine_distance(const float* x, const float* rx, int nx, const float* y, const float* ry,
+                            int ny, int ld, float* C, int ldc, void* stream) {
+  ST_CHECK_ARG(x && rx && y && ry && C && nx > 0 && ny > 0 && ldc >= ny, STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0 && ld > 0, STROTSS_EALIGN);
+  return st_cosine_distance(x, rx, nx, y, ry, ny, ld, C, ldc, (hipStream_t)stream);
+}
+
+size_t strotss_selfsim_workspace_bytes(int n) {
+  Workspace w = Workspace::planner();
+  SelfsimWs s;
+  s.plan(w, n);
+  return w.off;
+}
+
+int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int d, int ld, float gscale,
+                            float* gpred, float* loss_out, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  ST_CHECK_ARG(pred && content && gpred && loss_out && workspace && feat_ok(n, d, ld), STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  Workspace w(workspace, workspace_bytes);
+  SelfsimWs s;
+  ST_CHECK_ARG(s.plan(w, n), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  const int ldc = s.ldc;
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, content, n, ld, s.rc);
+  LAUNCH_OK();
+  CHK(st_cosine_distance(pred, s.rp, n, pred, s.rp, n, ld, s.Dx, ldc, st));
+  CHK(st_cosine_distance(content, s.rc, n, content, s.rc, n, ld, s.Dy, ldc, st));
+  hipLaunchKernelGGL(row_sum_kernel, dim3(n), dim3(256), 0, st, s.Dx, n, ldc, s.sx);
+  hipLaunchKernelGGL(row_sum_kernel, dim3(n), dim3(256), 0, st, s.Dy, n, ldc, s.sy);
+  // loss = mean(|A-B|) * n = (1/n) sum |A-B|  ->  dL/dA = sign/n
+  hipLaunchKernelGGL(selfsim_rowpass_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, n, ldc,
+                     1.0f / (float)n, s.Q, s.lossrow);
+  hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st, s.Q, s.Dx, s.rp, n, ldc, ldc, s.Mq,
+                     s.qdot);
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, s.lossrow, n, 1.0f / (float)n, loss_out);
+  LAUNCH_OK();
+  return st_selfsim_bwd_gemm(s.Mq, ldc, ldc, pred, s.rp, s.qdot, n, ld, gscale, gpred, st);
+}
+
+size_t strotss_remd_workspace_bytes(int ns, int n) {
+  Workspace w = Workspace::planner();
+  RemdWs s;
+  s.plan(w, ns, n);
+  return w.off;
+}
+
+int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n, int d,
+                             int ld, float gscale, float* gpred, float* loss_out, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(style && rs && pred && gpred && loss_out && workspace && ns > 0 && feat_ok(n, d, ld),
+               STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(ns <= REMD_MAX_LIST, STROTSS_ERANGE);
+  Workspace w(workspace, workspace_bytes);
+  RemdWs s;
+  ST_CHECK_ARG(s.plan(w, ns, n), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  const int ldc = s.ldc;
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+  LAUNCH_OK();
+  CHK(st_cosine_distance(style, rs, ns, pred, s.rp, n, ld, s.C, ldc, st));
+  hipLaunchKernelGGL(row_min_kernel, dim3(ns), dim3(256), 0, st, s.C, n, ldc, s.rmin, s.rcnt);
+  hipLaunchKernelGGL(col_min_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, s.C, ns, n, ldc, s.cmin, s.ccnt);
+  hipLaunchKernelGGL(remd_select_kernel, dim3(1), dim3(256), 0, st, s.rmin, ns, s.cmin, n, loss_out, s.sel);
+  hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldc, style, rs, ns, pred, s.rp, n,
+                     ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
+  ST_LAUNCH_RET();
+}
+
+int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld, float gscale,
+                                 float* gpred, float* loss_out, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  ST_CHECK_ARG(style && pred && gpred && loss_out && workspace && ns > 0 && n > 0 && ld >= 3, STROTSS_EINVAL);
+  Workspace w(workspace, workspace_bytes);
+  RemdWs s;
+  ST_CHECK_ARG(s.plan(w, ns, n), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  const int ldc = s.ldc;
+  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, st, style, ns, ld, s.ys);
+  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pred, n, ld, s.yp);
+  hipLaunchKernelGGL(palette_cost_kernel, dim3(cdiv(n, 256), ns), dim3(256), 0, st, s.ys, ns, s.yp, n, s.C,
+                     ldc);
+  hipLaunchKernelGGL(row_min_kernel, dim3(ns), dim3(256), 0, st, s.C, n, ldc, s.rmin, s.rcnt);
+  hipLaunchKernelGGL(col_min_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, s.C, ns, n, ldc, s.cmin, s.ccnt);
+  hipLaunchKernelGGL(remd_select_kernel, dim3(1), dim3(256), 0, st, s.rmin, ns, s.cmin, n, loss_out, s.sel);
+  hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, s.C, ldc, s.ys, ns, s.yp, n, s.rmin,
+                     s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred, ld);
+  ST_LAUNCH_RET();
+}
+
+size_t strotss_moment_workspace_bytes(int n, int ld) {
+  Workspace w = Workspace::planner();
+  MomentWs s;
+  s.plan(w, n, ld);
+  return w.off;
+}
+
+int strotss_moment_stats(const float* x, int n, int d, int ld, float* mean_out, float* cov_out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(x && mean_out && cov_out && workspace && feat_ok(n, d, ld), STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  Workspace w(workspace, workspace_bytes);
+  MomentWs s;
+  ST_CHECK_ARG(s.plan(w, n, ld), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(col_mean_kernel, dim3(cdiv(ld, 64)), dim3(256), 0, st, x, n, ld, mean_out);
+  hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st, x,
+                     n, s.rows, ld, mean_out, s.cy);
+  LAUNCH_OK();
+  return st_gram_tn(s.cy, s.rows, ld, 1.0f / (float)n, cov_out, st);
+}
+
+int strotss_moment_fwd_bwd(const float* style_mean, const float* style_cov, const float* pred, int n, int d,
+                           int ld, float gscale, float* gpred, float* loss_out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(style_mean && style_cov && pred && gpred && loss_out && workspace && feat_ok(n, d, ld),
+               STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  Workspace w(workspace, workspace_bytes);
+  MomentWs s;
+  ST_CHECK_ARG(s.plan(w, n, ld), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(col_mean_kernel, dim3(cdiv(ld, 64)), dim3(256), 0, st, pred, n, ld, s.mean);
+  hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st,
+                     pred, n, s.rows, ld, s.mean, s.cy);
+  LAUNCH_OK();
+  int n_partial = 0;
+  CHK(st_moment_fwd_gemm(s.cy, s.rows, ld, style_cov, s.T, 1.0f / (float)n, s.partial, &n_partial, st));
+  hipLaunchKernelGGL(moment_finalize_kernel, dim3(1), dim3(256), 0, st, s.partial, n_partial, style_mean,
+                     s.mean, d, ld, s.sgn, loss_out);
+  LAUNCH_OK();
+  // dL/dcy = cy (T + T^T) / (n d^2) = 2 cy T / (n d^2) (T symmetric); centring adjoint drops the
+  // column mean of dL/dcy, which is zero up to rounding because sum_i cy[i,:] = 0.
+  const float a = gscale * 2.0f / ((float)n * (float)d * (float)d);
+  const float b = gscale / ((float)d * (float)n);
+  return st_moment_bwd_gemm(s.cy, n, ld, s.T, a, s.sgn, b, gpred, st);
+}
+
+}  // extern "C"

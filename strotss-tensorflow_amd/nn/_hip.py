@@ -1,0 +1,147 @@
+"""ctypes binding of libstrotss_hip.so (C ABI: include/strotss_hip.h).
+
+This is the ONLY compute backend of the package: there is no CPU fallback.  Importing this
+module never fails (so argument parsing, the oracle-free host logic and the symbol-export test
+work on a machine without a GPU), but the first kernel call raises `StrotssHipError` when the
+library is missing or no MI355X is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstrotss_hip.so")
+
+MAX_MAPS, MAX_DIVS, MAX_TENSORS = 12, 8, 8
+
+
+class StrotssHipError(RuntimeError):
+    pass
+
+
+class MapsT(C.Structure):
+    _fields_ = [("n_maps", C.c_int),
+                ("h", C.c_int * MAX_MAPS), ("w", C.c_int * MAX_MAPS), ("c", C.c_int * MAX_MAPS),
+                ("n_div", C.c_int * MAX_MAPS),
+                ("div", C.c_float * MAX_DIVS),
+                ("map", C.c_void_p * MAX_MAPS),
+                ("gmap", C.c_void_p * MAX_MAPS)]
+
+
+class TensorsT(C.Structure):
+    _fields_ = [("n_tensors", C.c_int),
+                ("var", C.c_void_p * MAX_TENSORS), ("rms", C.c_void_p * MAX_TENSORS),
+                ("grad", C.c_void_p * MAX_TENSORS), ("numel", C.c_int64 * MAX_TENSORS)]
+
+
+_P, _I, _F, _Z, _L = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+# name -> (restype, argtypes); must list EVERY symbol include/strotss_hip.h declares
+SIGNATURES = {
+    "strotss_abi_version": (_I, []),
+    "strotss_build_info": (C.c_char_p, []),
+    "strotss_resize_bilinear": (_I, [_P, _I, _I, _I, _P, _I, _I, _F, _P, _P]),
+    "strotss_resize_bilinear_adjoint": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
+    "strotss_conv3x3_c3_fwd": (_I, [_P, _I, _I, _P, _P, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
+    "strotss_conv3x3_relu_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "strotss_conv3x3_dgrad": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "strotss_conv3x3_c3_dgrad": (_I, [_P, _I, _I, _I, _P, C.POINTER(_F), _P, _I, _P]),
+    "strotss_maxpool2_fwd": (_I, [_P, _I, _I, _I, _P, _P]),
+    "strotss_maxpool2_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "strotss_hypercol_gather": (_I, [C.POINTER(MapsT), _P, _I, _I, _P, _I, _P]),
+    "strotss_hypercol_scatter": (_I, [C.POINTER(MapsT), _P, _I, _P, _I, _I, _I, _I, _P]),
+    "strotss_row_inv_norm": (_I, [_P, _I, _I, _P, _P]),
+    "strotss_cosine_distance": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _I, _P]),
+    "strotss_selfsim_workspace_bytes": (_Z, [_I]),
+    "strotss_selfsim_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_remd_workspace_bytes": (_Z, [_I, _I]),
+    "strotss_remd_cos_fwd_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_palette_remd_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_moment_workspace_bytes": (_Z, [_I, _I]),
+    "strotss_moment_stats": (_I, [_P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "strotss_moment_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_rmsprop_step": (_I, [C.POINTER(TensorsT), _F, _F, _F, _P]),
+    "strotss_postprocess": (_I, [_P, _L, _P, _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the library and type every entry point.  Needs no GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise StrotssHipError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C strotss-tensorflow_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError -> missing export
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib() -> C.CDLL:
+    """The library, ready to launch kernels: fails loudly without a GPU."""
+    l = load_library()
+    if not torch.cuda.is_available():
+        raise StrotssHipError("no MI355X visible: libstrotss_hip kernels cannot run (no CPU fallback)")
+    return l
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "EINVAL", -2: "EALIGN", -3: "ERANGE"}.get(rc, f"hipError {rc}")
+        raise StrotssHipError(f"{what} failed: {kind}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def require(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise StrotssHipError(f"{name} must be a contiguous float32 CUDA/HIP tensor, got "
+                              f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t
+
+
+def make_maps(maps: Sequence[torch.Tensor], divs_per_map: Sequence[Sequence[float]],
+              gmaps: Optional[Sequence[torch.Tensor]] = None) -> MapsT:
+    """maps: list of (1,h,w,c) or (h,w,c) tensors; divs_per_map[k]: the divisor chain for map k
+    (each chain is a prefix of the longest one, as the reference's cumulative `indices /= y`)."""
+    if len(maps) > MAX_MAPS:
+        raise StrotssHipError("too many maps")
+    m = MapsT()
+    m.n_maps = len(maps)
+    longest = max(divs_per_map, key=len)
+    if len(longest) > MAX_DIVS:
+        raise StrotssHipError("divisor chain too long")
+    for i, d in enumerate(longest):
+        m.div[i] = d
+    for k, t in enumerate(maps):
+        require(t, f"map {k}")
+        h, w, c = t.shape[-3], t.shape[-2], t.shape[-1]
+        m.h[k], m.w[k], m.c[k] = h, w, c
+        chain = list(divs_per_map[k])
+        assert chain == list(longest[:len(chain)])
+        m.n_div[k] = len(chain)
+        m.map[k] = t.data_ptr()
+        if gmaps is not None and gmaps[k] is not None:
+            require(gmaps[k], f"gmap {k}")
+            assert gmaps[k].numel() == t.numel()
+            m.gmap[k] = gmaps[k].data_ptr()
+    return m

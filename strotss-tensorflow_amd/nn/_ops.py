@@ -1,0 +1,252 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of
+include/strotss_hip.h).  Tensors are torch HIP tensors used purely as device memory."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _hip
+from ._hip import check, ptr, require, stream_ptr
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)      # reference nn/model.py:34
+IMAGENET_STD = (0.229, 0.224, 0.225)       # reference nn/model.py:35
+_MEAN3 = (C.c_float * 3)(*IMAGENET_MEAN)
+_STD3 = (C.c_float * 3)(*IMAGENET_STD)
+
+
+def pad32(v: int) -> int:
+    return (v + 31) // 32 * 32
+
+
+def hwc(t: torch.Tensor) -> Tuple[int, int, int]:
+    return int(t.shape[-3]), int(t.shape[-2]), int(t.shape[-1])
+
+
+# ------------------------------------------------------------------ images
+def resize_bilinear(x: torch.Tensor, oh: int, ow: int, alpha: float = 1.0,
+                    add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    require(x, "resize input")
+    ih, iw, c = hwc(x)
+    shape = (*x.shape[:-3], oh, ow, c)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    if add is not None:
+        require(add, "resize addend")
+        assert add.numel() == out.numel()
+    check(_hip.lib().strotss_resize_bilinear(ptr(x), ih, iw, c, ptr(out), oh, ow, alpha, ptr(add),
+                                             stream_ptr()), "resize_bilinear")
+    return out
+
+
+def resize_bilinear_adjoint(gout: torch.Tensor, ih: int, iw: int,
+                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    require(gout, "resize adjoint input")
+    oh, ow, c = hwc(gout)
+    if out is None:
+        out = torch.empty((*gout.shape[:-3], ih, iw, c), dtype=torch.float32, device=gout.device)
+    check(_hip.lib().strotss_resize_bilinear_adjoint(ptr(gout), oh, ow, c, ptr(out), ih, iw, stream_ptr()),
+          "resize_bilinear_adjoint")
+    return out
+
+
+# ------------------------------------------------------------------ VGG layers
+def conv3x3_c3_fwd(img, w_kio, bias, out=None):
+    require(img, "image"); h, w, c = hwc(img)
+    assert c == 3
+    cout = bias.numel()
+    if out is None:
+        out = torch.empty((1, h, w, cout), dtype=torch.float32, device=img.device)
+    check(_hip.lib().strotss_conv3x3_c3_fwd(ptr(img), h, w, ptr(w_kio), ptr(bias), cout, _MEAN3, _STD3,
+                                            ptr(out), stream_ptr()), "conv3x3_c3_fwd")
+    return out
+
+
+def conv3x3_relu_fwd(x, w_tok, bias, out=None):
+    require(x, "conv input"); h, w, cin = hwc(x)
+    cout = bias.numel()
+    if out is None:
+        out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
+    check(_hip.lib().strotss_conv3x3_relu_fwd(ptr(x), h, w, cin, ptr(w_tok), ptr(bias), cout, ptr(out),
+                                              stream_ptr()), "conv3x3_relu_fwd")
+    return out
+
+
+def conv3x3_dgrad(gout, w_tik, cin, act_in=None, out=None):
+    require(gout, "conv grad"); h, w, cout = hwc(gout)
+    if out is None:
+        out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
+    check(_hip.lib().strotss_conv3x3_dgrad(ptr(gout), h, w, cout, ptr(w_tik), cin, ptr(act_in), ptr(out),
+                                           stream_ptr()), "conv3x3_dgrad")
+    return out
+
+
+def conv3x3_c3_dgrad(gout, w_tic, gimg=None, accumulate=False):
+    require(gout, "conv grad"); h, w, cout = hwc(gout)
+    if gimg is None:
+        gimg = torch.empty((1, h, w, 3), dtype=torch.float32, device=gout.device)
+        accumulate = False
+    check(_hip.lib().strotss_conv3x3_c3_dgrad(ptr(gout), h, w, cout, ptr(w_tic), _STD3, ptr(gimg),
+                                              int(accumulate), stream_ptr()), "conv3x3_c3_dgrad")
+    return gimg
+
+
+def maxpool2_fwd(x, out=None):
+    require(x, "pool input"); h, w, c = hwc(x)
+    if out is None:
+        out = torch.empty((1, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    check(_hip.lib().strotss_maxpool2_fwd(ptr(x), h, w, c, ptr(out), stream_ptr()), "maxpool2_fwd")
+    return out
+
+
+def maxpool2_bwd(act, gout, out=None):
+    require(act, "pool act"); require(gout, "pool grad"); h, w, c = hwc(act)
+    if out is None:
+        out = torch.empty_like(act)
+    check(_hip.lib().strotss_maxpool2_bwd(ptr(act), h, w, c, ptr(gout), ptr(out), stream_ptr()),
+          "maxpool2_bwd")
+    return out
+
+
+# ------------------------------------------------------------------ hypercolumns
+def map_divisors(shapes: Sequence[Tuple[int, int]]) -> List[List[float]]:
+    """Divisor chain per map: reference nn/strotss_utils.py:31-37 (`indices /= y`, cumulative, the
+    axis chosen once from whether log2 of the first shrunk height is an integer)."""
+    import math
+    chains, cur, index = [], [], None
+    for i, (h, w) in enumerate(shapes):
+        if i > 0 and h < shapes[i - 1][0]:
+            if index is None:
+                index = 0 if not (math.log2(h) % 1) else 1
+            cur = cur + [shapes[i - 1][index] / shapes[i][index]]
+        chains.append(list(cur))
+    return chains
+
+
+def hypercol_gather(maps: Sequence[torch.Tensor], idx: torch.Tensor, bilinear: bool,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> (pad32(n), pad32(D)) feature buffer, rows >= n and columns >= D zero."""
+    require(idx, "indices")
+    n = idx.shape[0]
+    d = sum(int(m.shape[-1]) for m in maps)
+    if out is None:
+        out = torch.zeros((pad32(n), pad32(d)), dtype=torch.float32, device=idx.device)
+    mt = _hip.make_maps(maps, map_divisors([hwc(m)[:2] for m in maps]))
+    check(_hip.lib().strotss_hypercol_gather(C.byref(mt), ptr(idx), n, int(bilinear), ptr(out),
+                                             out.shape[1], stream_ptr()), "hypercol_gather")
+    return out
+
+
+def hypercol_scatter(maps: Sequence[torch.Tensor], gmaps: Sequence[Optional[torch.Tensor]],
+                     idx: torch.Tensor, gfeat: torch.Tensor, relu_mask_from: int = 1,
+                     map_begin: int = 0, map_end: Optional[int] = None, maps_t=None):
+    """gmaps[k] += adjoint-gather of gfeat's columns of map k, for k in [map_begin, map_end)
+    (float atomics).  `maps_t` may carry a prebuilt descriptor (engine hot loop)."""
+    require(idx, "indices"); require(gfeat, "feature grads")
+    if map_end is None:
+        map_end = len(maps)
+    mt = maps_t if maps_t is not None else _hip.make_maps(
+        maps, map_divisors([hwc(m)[:2] for m in maps]), gmaps)
+    check(_hip.lib().strotss_hypercol_scatter(C.byref(mt), ptr(idx), idx.shape[0], ptr(gfeat),
+                                              gfeat.shape[1], relu_mask_from, map_begin, map_end,
+                                              stream_ptr()), "hypercol_scatter")
+
+
+# ------------------------------------------------------------------ losses
+class _WsCache:
+    """Grow-only workspace per (device, tag): the C ABI never allocates."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, tag: str, nbytes: int, device) -> torch.Tensor:
+        key = (tag, str(device))
+        b = self.bufs.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self.bufs[key] = b
+        return b
+
+
+workspaces = _WsCache()
+
+
+def row_inv_norm(x: torch.Tensor, n: int) -> torch.Tensor:
+    require(x, "features")
+    r = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+    check(_hip.lib().strotss_row_inv_norm(ptr(x), n, x.shape[1], ptr(r), stream_ptr()), "row_inv_norm")
+    return r
+
+
+def cosine_distance(x, rx, nx, y, ry, ny) -> torch.Tensor:
+    ldc = pad32(ny)
+    Cm = torch.empty((nx, ldc), dtype=torch.float32, device=x.device)
+    check(_hip.lib().strotss_cosine_distance(ptr(x), ptr(rx), nx, ptr(y), ptr(ry), ny, x.shape[1], ptr(Cm),
+                                             ldc, stream_ptr()), "cosine_distance")
+    return Cm
+
+
+def selfsim_fwd_bwd(pred, content, n, d, gscale, gpred, loss_out):
+    l = _hip.lib()
+    nb = l.strotss_selfsim_workspace_bytes(n)
+    ws = workspaces.get("selfsim", nb, pred.device)
+    check(l.strotss_selfsim_fwd_bwd(ptr(pred), ptr(content), n, d, pred.shape[1], gscale, ptr(gpred),
+                                    ptr(loss_out), ptr(ws), nb, stream_ptr()), "selfsim_fwd_bwd")
+
+
+def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out):
+    l = _hip.lib()
+    nb = l.strotss_remd_workspace_bytes(ns, n)
+    ws = workspaces.get("remd", nb, pred.device)
+    check(l.strotss_remd_cos_fwd_bwd(ptr(style), ptr(rs), ns, ptr(pred), n, d, pred.shape[1], gscale,
+                                     ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "remd_cos_fwd_bwd")
+
+
+def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out):
+    l = _hip.lib()
+    nb = l.strotss_remd_workspace_bytes(ns, n)
+    ws = workspaces.get("remd", nb, pred.device)
+    assert style.shape[1] == pred.shape[1]
+    check(l.strotss_palette_remd_fwd_bwd(ptr(style), ns, ptr(pred), n, pred.shape[1], gscale, ptr(gpred),
+                                         ptr(loss_out), ptr(ws), nb, stream_ptr()), "palette_remd_fwd_bwd")
+
+
+def moment_stats(x, n, d):
+    l = _hip.lib()
+    ld = x.shape[1]
+    nb = l.strotss_moment_workspace_bytes(n, ld)
+    ws = workspaces.get("moment", nb, x.device)
+    mean = torch.empty(ld, dtype=torch.float32, device=x.device)
+    cov = torch.empty((ld, ld), dtype=torch.float32, device=x.device)
+    check(l.strotss_moment_stats(ptr(x), n, d, ld, ptr(mean), ptr(cov), ptr(ws), nb, stream_ptr()),
+          "moment_stats")
+    return mean, cov
+
+
+def moment_fwd_bwd(style_mean, style_cov, pred, n, d, gscale, gpred, loss_out):
+    l = _hip.lib()
+    ld = pred.shape[1]
+    nb = l.strotss_moment_workspace_bytes(n, ld)
+    ws = workspaces.get("moment", nb, pred.device)
+    check(l.strotss_moment_fwd_bwd(ptr(style_mean), ptr(style_cov), ptr(pred), n, d, ld, gscale, ptr(gpred),
+                                   ptr(loss_out), ptr(ws), nb, stream_ptr()), "moment_fwd_bwd")
+
+
+# ------------------------------------------------------------------ optimiser / output
+def rmsprop_step(variables, rms, grads, lr: float, rho: float = 0.99, eps: float = 1e-8):
+    t = _hip.TensorsT()
+    t.n_tensors = len(variables)
+    for k, (v, r, g) in enumerate(zip(variables, rms, grads)):
+        require(v, "variable"); require(r, "rms"); require(g, "grad")
+        assert v.numel() == r.numel() == g.numel()
+        t.var[k], t.rms[k], t.grad[k], t.numel[k] = v.data_ptr(), r.data_ptr(), g.data_ptr(), v.numel()
+    check(_hip.lib().strotss_rmsprop_step(C.byref(t), lr, rho, eps, stream_ptr()), "rmsprop_step")
+
+
+def postprocess(img: torch.Tensor) -> torch.Tensor:
+    require(img, "image")
+    out = torch.empty(img.shape, dtype=torch.uint8, device=img.device)
+    ws = torch.empty(2048, dtype=torch.float32, device=img.device)
+    check(_hip.lib().strotss_postprocess(ptr(img), img.numel(), ptr(out), ptr(ws), stream_ptr()), "postprocess")
+    return out

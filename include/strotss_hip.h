@@ -133,10 +133,13 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
                              int d, int ld, float gscale, float* gpred, float* loss_out,
                              void* workspace, size_t workspace_bytes, void* stream);
 /* loss_out[0] = relaxed_emd(yuv(style[:, :3]), yuv(pred[:, :3]), 'both') (run_strotss.py:37-39);
- * gpred[:, :3] += gscale*dloss/dpred[:, :3].  style/pred are the full (rows, ld) matrices. */
+ * gpred[:, :3] += gscale*dloss/dpred[:, :3].  style/pred are the full (rows, ld) matrices, of
+ * which only the first three columns are read.  rgb_to_yuv != 0 applies convert_rgb_to_yuv
+ * (strotss_utils.py:166-167) to them first; 0 takes them as they are (losses.relaxed_emd 'both').
+ * Workspace: strotss_remd_workspace_bytes(ns, n). */
 int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld,
-                                 float gscale, float* gpred, float* loss_out, void* workspace,
-                                 size_t workspace_bytes, void* stream);
+                                 int rgb_to_yuv, float gscale, float* gpred, float* loss_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 size_t strotss_moment_workspace_bytes(int n, int ld);
 /* style side of moment_matching, once per scale: mean_out(ld), cov_out(ld,ld) = biased covariance */
 int strotss_moment_stats(const float* x, int n, int d, int ld, float* mean_out, float* cov_out,

@@ -213,14 +213,17 @@ __global__ __launch_bounds__(256) void remd_cos_bwd_kernel(
 // ---------------------------------------------------------------- palette (D = 3, pure VALU)
 // yuv[i] = (Y, U, V, r) with r the inverse norm of the YUV vector  (strotss_utils.py:166-167)
 __global__ __launch_bounds__(256) void palette_prepare_kernel(const float* __restrict__ feat, int n, int ld,
-                                                              f32x4* __restrict__ yuv) {
+                                                              f32x4* __restrict__ yuv, int convert) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float* p = feat + (size_t)i * ld;
   const float R = p[0], G = p[1], B = p[2];
-  const float Y = R * 0.299f + G * 0.587f + B * 0.114f;
-  const float U = R * -0.14714119f + G * -0.28886916f + B * 0.43601035f;
-  const float V = R * 0.61497538f + G * -0.51496512f + B * -0.10001026f;
+  float Y = R, U = G, V = B;
+  if (convert) {
+    Y = R * 0.299f + G * 0.587f + B * 0.114f;
+    U = R * -0.14714119f + G * -0.28886916f + B * 0.43601035f;
+    V = R * 0.61497538f + G * -0.51496512f + B * -0.10001026f;
+  }
   const float ss = Y * Y + U * U + V * V;
   f32x4 o = {Y, U, V, 1.0f / sqrtf(fmaxf(ss, 1e-12f))};
   yuv[i] = o;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(64) void palette_bwd_kernel(
     const float* __restrict__ C, int ldc, const f32x4* __restrict__ ys, int ns, const f32x4* __restrict__ yp,
     int n, const float* __restrict__ rmin, const float* __restrict__ rcnt, const float* __restrict__ cmin,
     const float* __restrict__ ccnt, const int* __restrict__ sel, float gscale, float* __restrict__ gpred,
-    int ld) {
+    int ld, int convert) {
   const int j = blockIdx.x, lane = threadIdx.x;
   const int row_branch = sel[0];
   const f32x4 y = yp[j];
@@ -281,9 +284,13 @@ __global__ __launch_bounds__(64) void palette_bwd_kernel(
     const float d2 = rj * (gh2 - y[2] * rj * q * live) + sk * y[2] - kx2;
     // back through yuv = rgb @ M :  d_rgb = d_yuv @ M^T
     float* g = gpred + (size_t)j * ld;
-    g[0] += gscale * (d0 * 0.299f + d1 * -0.14714119f + d2 * 0.61497538f);
-    g[1] += gscale * (d0 * 0.587f + d1 * -0.28886916f + d2 * -0.51496512f);
-    g[2] += gscale * (d0 * 0.114f + d1 * 0.43601035f + d2 * -0.10001026f);
+    if (convert) {
+      g[0] += gscale * (d0 * 0.299f + d1 * -0.14714119f + d2 * 0.61497538f);
+      g[1] += gscale * (d0 * 0.587f + d1 * -0.28886916f + d2 * -0.51496512f);
+      g[2] += gscale * (d0 * 0.114f + d1 * 0.43601035f + d2 * -0.10001026f);
+    } else {
+      g[0] += gscale * d0; g[1] += gscale * d1; g[2] += gscale * d2;
+    }
   }
 }
 
@@ -474,24 +481,24 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   ST_LAUNCH_RET();
 }
 
-int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld, float gscale,
-                                 float* gpred, float* loss_out, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld, int rgb_to_yuv,
+                                 float gscale, float* gpred, float* loss_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(style && pred && gpred && loss_out && workspace && ns > 0 && n > 0 && ld >= 3, STROTSS_EINVAL);
   Workspace w(workspace, workspace_bytes);
   RemdWs s;
   ST_CHECK_ARG(s.plan(w, ns, n), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
   const int ldc = s.ldc;
-  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, st, style, ns, ld, s.ys);
-  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pred, n, ld, s.yp);
+  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, st, style, ns, ld, s.ys, rgb_to_yuv);
+  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pred, n, ld, s.yp, rgb_to_yuv);
   hipLaunchKernelGGL(palette_cost_kernel, dim3(cdiv(n, 256), ns), dim3(256), 0, st, s.ys, ns, s.yp, n, s.C,
                      ldc);
   hipLaunchKernelGGL(row_min_kernel, dim3(ns), dim3(256), 0, st, s.C, n, ldc, s.rmin, s.rcnt);
   hipLaunchKernelGGL(col_min_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, s.C, ns, n, ldc, s.cmin, s.ccnt);
   hipLaunchKernelGGL(remd_select_kernel, dim3(1), dim3(256), 0, st, s.rmin, ns, s.cmin, n, loss_out, s.sel);
   hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, s.C, ldc, s.ys, ns, s.yp, n, s.rmin,
-                     s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred, ld);
+                     s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred, ld, rgb_to_yuv);
   ST_LAUNCH_RET();
 }
 

@@ -52,14 +52,18 @@ def resize_bilinear_adjoint(gout: torch.Tensor, ih: int, iw: int,
 
 
 # ------------------------------------------------------------------ VGG layers
-def conv3x3_c3_fwd(img, w_kio, bias, out=None):
+def _f3(v, default):
+    return default if v is None else (C.c_float * 3)(*v)
+
+
+def conv3x3_c3_fwd(img, w_kio, bias, out=None, mean=None, std=None):
     require(img, "image"); h, w, c = hwc(img)
     assert c == 3
     cout = bias.numel()
     if out is None:
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=img.device)
-    check(_hip.lib().strotss_conv3x3_c3_fwd(ptr(img), h, w, ptr(w_kio), ptr(bias), cout, _MEAN3, _STD3,
-                                            ptr(out), stream_ptr()), "conv3x3_c3_fwd")
+    check(_hip.lib().strotss_conv3x3_c3_fwd(ptr(img), h, w, ptr(w_kio), ptr(bias), cout, _f3(mean, _MEAN3),
+                                            _f3(std, _STD3), ptr(out), stream_ptr()), "conv3x3_c3_fwd")
     return out
 
 
@@ -82,12 +86,12 @@ def conv3x3_dgrad(gout, w_tik, cin, act_in=None, out=None):
     return out
 
 
-def conv3x3_c3_dgrad(gout, w_tic, gimg=None, accumulate=False):
+def conv3x3_c3_dgrad(gout, w_tic, gimg=None, accumulate=False, std=None):
     require(gout, "conv grad"); h, w, cout = hwc(gout)
     if gimg is None:
         gimg = torch.empty((1, h, w, 3), dtype=torch.float32, device=gout.device)
         accumulate = False
-    check(_hip.lib().strotss_conv3x3_c3_dgrad(ptr(gout), h, w, cout, ptr(w_tic), _STD3, ptr(gimg),
+    check(_hip.lib().strotss_conv3x3_c3_dgrad(ptr(gout), h, w, cout, ptr(w_tic), _f3(std, _STD3), ptr(gimg),
                                               int(accumulate), stream_ptr()), "conv3x3_c3_dgrad")
     return gimg
 
@@ -203,13 +207,13 @@ def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out):
                                      ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "remd_cos_fwd_bwd")
 
 
-def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out):
+def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out, rgb_to_yuv=True):
     l = _hip.lib()
     nb = l.strotss_remd_workspace_bytes(ns, n)
     ws = workspaces.get("remd", nb, pred.device)
     assert style.shape[1] == pred.shape[1]
-    check(l.strotss_palette_remd_fwd_bwd(ptr(style), ns, ptr(pred), n, pred.shape[1], gscale, ptr(gpred),
-                                         ptr(loss_out), ptr(ws), nb, stream_ptr()), "palette_remd_fwd_bwd")
+    check(l.strotss_palette_remd_fwd_bwd(ptr(style), ns, ptr(pred), n, pred.shape[1], int(rgb_to_yuv), gscale,
+                                         ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "palette_remd_fwd_bwd")
 
 
 def moment_stats(x, n, d):

@@ -1,0 +1,232 @@
+"""The optimisation inner loop of run_strotss.py:104-148 as an explicit, pre-allocated kernel
+sequence on one HIP stream (no tracing compiler, no autograd tape):
+
+    fold (5 resize+add)  ->  VGG trunk forward  ->  hypercolumn gather (content, prediction)
+    ->  self-similarity / moment / REMD / palette fused forward+backward into one (N, D) gradient
+    ->  trunk data-gradient with the taps' scatter-adds interleaved  ->  pixel gradient
+    ->  [RCCL all-reduce of the pixel gradient when mask regions are sharded over GPUs]
+    ->  fold adjoint (5 transposed resizes)  ->  one multi-tensor RMSprop launch.
+
+Nothing in `step()` synchronises with the host; the three logged scalars stay on the device until
+`losses()` is called.  Index sets are inputs (reference: drawn inside the traced train_step,
+strotss_utils.py:83-121), so identical index streams give comparable trajectories.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _hip, _ops
+from .model import VGGParams, VGGTrunk
+
+
+@dataclass
+class StyleTarget:
+    """Style side of StyleLoss (run_strotss.py:27-31): sampled once per scale, then constant."""
+    feats: torch.Tensor      # (pad32(ns), ld)
+    ns: int
+    inv_norm: torch.Tensor   # row_inv_norm(feats)
+    mean: torch.Tensor       # (ld,)
+    cov: torch.Tensor        # (ld, ld)
+
+    @staticmethod
+    def build(feats: torch.Tensor, ns: int, d: int) -> "StyleTarget":
+        rs = _ops.row_inv_norm(feats, ns)
+        mean, cov = _ops.moment_stats(feats, ns, d)
+        return StyleTarget(feats, ns, rs, mean, cov)
+
+
+def extract_features(params: VGGParams, image: torch.Tensor) -> List[torch.Tensor]:
+    """[image] + vgg(image)  (run_strotss.py:95-96), taps cloned out of a temporary trunk."""
+    h, w = int(image.shape[1]), int(image.shape[2])
+    trunk = VGGTrunk(params, h, w, with_grad=False)
+    img = image.contiguous()
+    return [img] + [t.clone() for t in trunk.forward(img)]
+
+
+class StepEngine:
+    """One scale of the coarse-to-fine loop: owns the 6 pyramid variables and their RMSprop slots.
+
+    `regions` > 1 is the masked path (run_strotss.py:104-125): one trunk forward/backward, one
+    index set + loss group per region, loss = mean over regions.  With `dist_group`, regions are
+    dealt round-robin to the ranks and the pixel gradient is all-reduced (sum) before the fold
+    adjoint, so every rank applies the identical update."""
+
+    N_SCALARS = 4   # loss_c, l_moment, l_remd, l_palette per region
+
+    def __init__(self, params: VGGParams, content_feat: Sequence[torch.Tensor],
+                 style_targets: Sequence[StyleTarget], stylized: torch.Tensor, alpha: float,
+                 loss_denom: float, lr: float, sample_size: int = 1024, levels: int = 5,
+                 dist_group=None, rho: float = 0.99, eps: float = 1e-8):
+        dev = stylized.device
+        self.params = params
+        self.alpha, self.loss_denom, self.lr, self.rho, self.eps = float(alpha), float(loss_denom), float(lr), rho, eps
+        self.inv_alpha = 1.0 / max(self.alpha, 1.0)
+        self.content_feat = [c.contiguous() for c in content_feat]
+        self.style_targets = list(style_targets)
+        self.R = len(self.style_targets)
+        h, w = int(stylized.shape[1]), int(stylized.shape[2])
+        self.h, self.w = h, w
+        # --- variables = make_laplacian_pyramid(stylized) (run_strotss.py:89), rms slots start at 0
+        from .strotss_utils import make_laplacian_pyramid
+        self.variables = [v.contiguous() for v in make_laplacian_pyramid(stylized.contiguous(), levels)]
+        self.rms = [torch.zeros_like(v) for v in self.variables]
+        self.sizes = [(int(v.shape[1]), int(v.shape[2])) for v in self.variables]
+        # fold temporaries: f[k] = v[k] + up(f[k+1]); f[0] is the image
+        self.fold = [torch.empty_like(v) for v in self.variables[:-1]]
+        self.trunk = VGGTrunk(params, h, w, with_grad=True)
+        self.d = 3 + sum(int(a.shape[-1]) for a in (self.trunk.acts[i] for i in self.trunk.taps))
+        self.ld = _ops.pad32(self.d)
+        rows = _ops.pad32(sample_size)
+        self.sample_size = sample_size
+        self.cf = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
+        self.pf = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
+        self.gp = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
+        self.scalars = torch.zeros((self.R, 8), dtype=torch.float32, device=dev)
+        # gradient of the variables: level 0 aliases the pixel gradient
+        self.gvars = [self.trunk.gimg] + [torch.empty_like(v) for v in self.variables[1:]]
+        # hypercolumn descriptors (pointers are static for the life of the engine)
+        self.pred_maps = [self.fold[0]] + [self.trunk.acts[i] for i in self.trunk.taps]
+        gmaps = [self.trunk.gimg] + [self.trunk.grads[i] for i in self.trunk.taps]
+        shapes = [_ops.hwc(m)[:2] for m in self.pred_maps]
+        self.divs = _ops.map_divisors(shapes)
+        self._mt_pred = _hip.make_maps(self.pred_maps, self.divs, gmaps)
+        self._mt_content = _hip.make_maps(self.content_feat, self.divs)
+        self._layer_to_map = {li: k + 1 for k, li in enumerate(self.trunk.taps)}
+        self._layer_to_map[-1] = 0
+        # region sharding
+        self.group = dist_group
+        if dist_group is not None:
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(dist_group), dist.get_world_size(dist_group)
+        else:
+            self.rank, self.world = 0, 1
+        self.my_regions = list(range(self.rank, self.R, self.world))
+        self._idx: List[Optional[torch.Tensor]] = [None] * self.R
+        self.steps_done = 0
+
+    # ------------------------------------------------------------------ pieces of the step
+    def fold_forward(self) -> torch.Tensor:
+        """img = fold_laplacian_pyramid(variables)   (strotss_utils.py:159-163)"""
+        t = self.variables[-1]
+        for k in range(len(self.variables) - 2, -1, -1):
+            hk, wk = self.sizes[k]
+            _ops.resize_bilinear(t, hk, wk, 1.0, self.variables[k], out=self.fold[k])
+            t = self.fold[k]
+        return self.fold[0]
+
+    def _gather(self, maps_t, idx, out):
+        n = idx.shape[0]
+        _hip.check(_hip.lib().strotss_hypercol_gather(_hip.C.byref(maps_t), idx.data_ptr(), n, 1, out.data_ptr(),
+                                                      self.ld, _hip.stream_ptr()), "hypercol_gather")
+
+    def _losses(self, r: int, n: int):
+        """(alpha*loss_c + loss_s)/loss_denom/R and its gradient w.r.t. the sampled prediction."""
+        st = self.style_targets[r]
+        pf, cf, gp, sc = self.pf[r], self.cf[r], self.gp[r], self.scalars[r]
+        if n < pf.shape[0]:
+            pf[n:].zero_(); cf[n:].zero_()
+        gp.zero_()
+        base = 1.0 / (self.loss_denom * self.R)
+        _ops.selfsim_fwd_bwd(pf, cf, n, self.d, self.alpha * base, gp, sc[0:])
+        _ops.moment_fwd_bwd(st.mean, st.cov, pf, n, self.d, base, gp, sc[1:])
+        _ops.remd_cos_fwd_bwd(st.feats, st.inv_norm, st.ns, pf, n, self.d, base, gp, sc[2:])
+        _ops.palette_remd_fwd_bwd(st.feats, st.ns, pf, n, self.inv_alpha * base, gp, sc[3:])
+
+    def _scatter(self, layer_index: int):
+        k = self._layer_to_map[layer_index]
+        for r in self.my_regions:
+            idx = self._idx[r]
+            _ops.hypercol_scatter(self.pred_maps, None, idx, self.gp[r], relu_mask_from=1, map_begin=k,
+                                  map_end=k + 1, maps_t=self._mt_pred)
+
+    def forward_backward(self, indices: Sequence[torch.Tensor]) -> None:
+        """train_step (run_strotss.py:131-142 / 104-125): fills self.gvars and self.scalars."""
+        assert len(indices) == self.R
+        img = self.fold_forward()
+        self.trunk.forward(img)
+        for r in self.my_regions:
+            idx = _hip.require(indices[r], "indices")
+            n = int(idx.shape[0])
+            assert 0 < n <= self.sample_size and idx.shape[1] == 2
+            self._idx[r] = idx
+            self._gather(self._mt_content, idx, self.cf[r])
+            self._gather(self._mt_pred, idx, self.pf[r])
+            self._losses(r, n)
+        if self.my_regions:
+            gimg = self.trunk.backward(self._scatter)
+        else:
+            gimg = self.trunk.gimg.zero_()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(gimg, group=self.group)          # one RCCL all-reduce on the pixel gradient
+            dist.all_reduce(self.scalars, group=self.group)   # (tiny) so every rank can log
+        # adjoint of the fold: gvars[k] = up^T(gvars[k-1])
+        for k in range(1, len(self.variables)):
+            hk, wk = self.sizes[k]
+            _ops.resize_bilinear_adjoint(self.gvars[k - 1], hk, wk, out=self.gvars[k])
+
+    def apply_gradients(self) -> None:
+        """opt.apply_gradients (run_strotss.py:148): Keras RMSprop, all 6 tensors in one launch."""
+        _ops.rmsprop_step(self.variables, self.rms, self.gvars, self.lr, self.rho, self.eps)
+
+    def step(self, indices: Sequence[torch.Tensor]) -> None:
+        self.forward_backward(indices)
+        self.apply_gradients()
+        self.steps_done += 1
+
+    # ------------------------------------------------------------------ read-outs (host sync)
+    def losses(self) -> dict:
+        s = self.scalars.detach().cpu().numpy().astype(np.float64)
+        lc = s[:, 0]
+        ls = s[:, 1] + s[:, 2] + self.inv_alpha * s[:, 3]
+        loss = ((self.alpha * lc + ls) / self.loss_denom).mean()
+        return {"loss": float(loss), "loss_c": float(lc.mean()), "loss_s": float(ls.mean()),
+                "l_moment": float(s[:, 1].mean()), "l_remd": float(s[:, 2].mean()),
+                "l_palette": float(s[:, 3].mean())}
+
+    def stylized(self) -> torch.Tensor:
+        return self.fold_forward().clone()
+
+
+# -------------------------------------------------------------------------------------------
+def smoke_check(O, np_, torch_) -> None:
+    """__graft_entry__.smoke(): one tiny optimisation step on cuda:0 checked against the oracle."""
+    from .model import synthetic_weights
+    dev = torch_.device("cuda", 0)
+    torch_.cuda.set_device(dev)
+    g = torch_.Generator().manual_seed(0)
+    content = torch_.rand(1, 32, 32, 3, generator=g, dtype=torch_.float32)
+    style = torch_.rand(1, 32, 32, 3, generator=g, dtype=torch_.float32)
+    weights = synthetic_weights('16', 0)
+    rng = np_.random.default_rng(0)
+    s_idx = O.make_indices(32, 32, False, 256, rng)
+    idx = O.make_indices(32, 32, True, 256, rng)
+    alpha, denom, lr = 16.0, 18.0625, 2e-3
+    # oracle (float64)
+    vgg = O.VGG(weights, dtype=torch_.float64)
+    c64, s64 = content.double(), style.double()
+    with torch_.no_grad():
+        cf = [c64] + vgg(c64); sf = [s64] + vgg(s64)
+        ss = O.sample_features(sf, s_idx, False)
+    init = O.make_laplacian(c64) + s64.mean(dim=(1, 2), keepdim=True)
+    variables = [v.clone().requires_grad_(True) for v in O.make_laplacian_pyramid(init)]
+    ref = O.train_step(variables, vgg, cf, ss, idx, alpha, denom)
+    # HIP
+    params = VGGParams(weights, '16', None, dev)
+    cfeat = extract_features(params, content.to(dev))
+    sfeat = extract_features(params, style.to(dev))
+    sfe = _ops.hypercol_gather(sfeat, torch_.from_numpy(s_idx).to(dev), False)
+    st = StyleTarget.build(sfe, s_idx.shape[0], 2179)
+    eng = StepEngine(params, cfeat, [st], init.float().to(dev), alpha, denom, lr, sample_size=256)
+    eng.step([torch_.from_numpy(idx).to(dev)])
+    torch_.cuda.synchronize()
+    got = eng.losses()
+    assert abs(got["loss"] - float(ref["loss"])) < 1e-4 * max(1.0, abs(float(ref["loss"]))), (got, float(ref["loss"]))
+    g0 = eng.gvars[0].cpu().double()
+    rel = float((g0 - ref["grads"][0]).norm() / ref["grads"][0].norm())
+    assert rel < 2e-2, rel
+    print(f"smoke ok: loss {got['loss']:.6f} (oracle {float(ref['loss']):.6f}), pixel-grad rel err {rel:.2e}")

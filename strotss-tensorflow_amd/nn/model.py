@@ -1,0 +1,277 @@
+"""VGG feature extractor on the HIP conv kernels -- mirrors the reference's nn/model.py:17-55.
+
+`VGG(layers=None, vgg_type='16', use_keras_weight=False, name=None)` keeps the reference
+signature and returns the same 9 post-ReLU taps from `__call__(inputs)` for an NHWC [0,1] RGB
+image.  Differences forced by the environment (documented in DESIGN.md):
+  * the reference downloads `vgg16_norm.h5` at construction (model.py:31-33); there is no network
+    here, so weights come from `weights=` (an .npz with HWIO kernels, see `load_weights`) or are
+    seeded He-normal synthetic ones (`seed=`);
+  * tensors are torch HIP tensors.
+The trunk is frozen (model.py:45): only the data gradient exists.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _ops
+
+_STROTSS_DEFAULTS = ['block1_conv1', 'block1_conv2', 'block2_conv1', 'block2_conv2', 'block3_conv1',
+                     'block3_conv2', 'block3_conv3', 'block4_conv3', 'block5_conv3']
+
+_BLOCKS = {'16': (2, 2, 3, 3, 3), '19': (2, 2, 4, 4, 4)}
+_WIDTHS = (64, 128, 256, 512, 512)
+
+
+def vgg_config(vgg_type: str = '16') -> List:
+    """[('block1_conv1', 3, 64), ..., 'pool', ...] in Keras layer order (include_top=False)."""
+    cfg, cin = [], 3
+    for b, (reps, width) in enumerate(zip(_BLOCKS[str(vgg_type)], _WIDTHS), start=1):
+        for r in range(1, reps + 1):
+            cfg.append((f'block{b}_conv{r}', cin, width))
+            cin = width
+        cfg.append('pool')
+    return cfg
+
+
+def synthetic_weights(vgg_type: str = '16', seed: int = 0) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    """Seeded He-normal HWIO kernels + small biases (same generator order as the oracle's
+    make_synthetic_vgg16_weights so both sides see identical numbers)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for item in vgg_config(vgg_type):
+        if item == 'pool':
+            continue
+        _, cin, cout = item
+        w = torch.randn(3, 3, cin, cout, generator=g, dtype=torch.float32) * math.sqrt(2.0 / (9 * cin))
+        b = torch.randn(cout, generator=g, dtype=torch.float32) * 0.05
+        out.append((w, b))
+    return out
+
+
+def load_weights(path: str, vgg_type: str = '16') -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    """.npz with arrays `<layer>/kernel` (3,3,Cin,Cout HWIO, the Keras layout) and `<layer>/bias`,
+    or torchvision-style `features.<i>.weight` (Cout,Cin,3,3) / `.bias` in layer order."""
+    z = np.load(path)
+    names = [it[0] for it in vgg_config(vgg_type) if it != 'pool']
+    out = []
+    if f'{names[0]}/kernel' in z:
+        for n in names:
+            out.append((torch.from_numpy(z[f'{n}/kernel']).float(), torch.from_numpy(z[f'{n}/bias']).float()))
+        return out
+    keys = sorted((k for k in z.files if k.endswith('.weight')), key=lambda k: int(k.split('.')[1]))
+    for k in keys[:len(names)]:
+        w = torch.from_numpy(z[k]).float().permute(2, 3, 1, 0).contiguous()   # OIHW -> HWIO
+        out.append((w, torch.from_numpy(z[k.replace('.weight', '.bias')]).float()))
+    return out
+
+
+class VGGParams:
+    """Frozen weights on the device in the layouts the kernels want (built once)."""
+
+    def __init__(self, weights: Sequence[Tuple[torch.Tensor, torch.Tensor]], vgg_type: str = '16',
+                 layers: Optional[Sequence[str]] = None, device="cuda", use_keras_weight: bool = False):
+        self.cfg = vgg_config(vgg_type)
+        self.tap_names = list(layers or _STROTSS_DEFAULTS)
+        names = [it[0] for it in self.cfg if it != 'pool']
+        for t in self.tap_names:
+            assert t in names, f"unknown layer {t}"
+        # drop everything after the last tapped layer: it can never influence a tap
+        last = max(names.index(t) for t in self.tap_names)
+        cut, seen = [], 0
+        for it in self.cfg:
+            if it != 'pool':
+                if seen > last:
+                    break
+                seen += 1
+            cut.append(it)
+        while cut and cut[-1] == 'pool':
+            cut.pop()
+        self.cfg = cut
+        if use_keras_weight:
+            # keras.applications.vgg16.preprocess_input(x*255): RGB->BGR, minus the BGR means, no
+            # std (model.py:38).  Equivalent: (x - m/255) / (1/255) with the kernel's ci flipped.
+            self.mean = tuple(v / 255.0 for v in (123.68, 116.779, 103.939))
+            self.std = (1 / 255.0,) * 3
+        else:
+            self.mean, self.std = _ops.IMAGENET_MEAN, _ops.IMAGENET_STD
+        self.layers = []
+        li = 0
+        for it in self.cfg:
+            if it == 'pool':
+                continue
+            name, cin, cout = it
+            w, b = weights[li]
+            li += 1
+            assert tuple(w.shape) == (3, 3, cin, cout), (name, tuple(w.shape))
+            w = w.float()
+            if use_keras_weight and cin == 3:
+                w = w.flip(2)
+            L = {"name": name, "cin": cin, "cout": cout, "bias": b.float().contiguous().to(device)}
+            if cin == 3:
+                L["w_fwd"] = w.reshape(27, cout).contiguous().to(device)                  # (27, cout)
+                L["w_bwd"] = w.flip(0, 1).reshape(9, 3, cout).contiguous().to(device)      # (9, 3, cout)
+            else:
+                L["w_fwd"] = w.permute(0, 1, 3, 2).reshape(9, cout, cin).contiguous().to(device)   # (9,cout,cin)
+                L["w_bwd"] = w.flip(0, 1).reshape(9, cin, cout).contiguous().to(device)           # (9,cin,cout)
+            self.layers.append(L)
+        self.device = device
+
+    @property
+    def tap_layer_indices(self) -> List[int]:
+        names = [L["name"] for L in self.layers]
+        return [names.index(t) for t in self.tap_names]
+
+
+class VGGTrunk:
+    """Pre-allocated forward/backward of the trunk for one image size.
+
+    forward(img) fills `acts` and returns the tapped maps (views, no copies).
+    backward(scatter) walks the layers in reverse: `scatter(layer_index)` is called right after
+    the gradient buffer of a tapped layer is complete from above, and must ADD the hypercolumn
+    gradient of that tap into `grads[layer_index]` (ReLU-masked); returns the pixel gradient buffer
+    into which `scatter(-1)` has added the image-channel part."""
+
+    def __init__(self, params: VGGParams, h: int, w: int, with_grad: bool = True):
+        self.p = params
+        dev = params.device
+        self.h, self.w = h, w
+        self.acts: List[torch.Tensor] = []
+        self.pools: List[torch.Tensor] = []
+        self.plan = []     # ('conv', layer_idx, src) | ('pool', pool_idx, src_layer)
+        ch, cw = h, w
+        li = pi = 0
+        src = ('img', 0)
+        for it in params.cfg:
+            if it == 'pool':
+                self.pools.append(torch.empty((1, ch // 2, cw // 2, self.acts[-1].shape[-1]), dtype=torch.float32, device=dev))
+                self.plan.append(('pool', pi, li - 1))
+                src = ('pool', pi)
+                pi += 1
+                ch, cw = ch // 2, cw // 2
+                if ch < 1 or cw < 1:
+                    raise ValueError(f"image {h}x{w} too small for this VGG depth")
+            else:
+                self.acts.append(torch.empty((1, ch, cw, it[2]), dtype=torch.float32, device=dev))
+                self.plan.append(('conv', li, src))
+                src = ('conv', li)
+                li += 1
+        self.taps = params.tap_layer_indices
+        self.with_grad = with_grad
+        if with_grad:
+            self.grads = [torch.empty_like(a) for a in self.acts]
+            self.gpools = [torch.empty_like(p) for p in self.pools]
+            self.gimg = torch.empty((1, h, w, 3), dtype=torch.float32, device=dev)
+        self.img = None
+
+    def _src(self, src):
+        kind, i = src
+        return self.img if kind == 'img' else (self.acts[i] if kind == 'conv' else self.pools[i])
+
+    def forward(self, img: torch.Tensor) -> List[torch.Tensor]:
+        self.img = img
+        P = self.p
+        for step in self.plan:
+            if step[0] == 'pool':
+                _ops.maxpool2_fwd(self.acts[step[2]], out=self.pools[step[1]])
+            else:
+                _, li, src = step
+                L = P.layers[li]
+                x = self._src(src)
+                if L["cin"] == 3:
+                    _ops.conv3x3_c3_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li], mean=P.mean, std=P.std)
+                else:
+                    _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
+        return [self.acts[i] for i in self.taps]
+
+    def backward(self, scatter: Callable[[int], None]) -> torch.Tensor:
+        assert self.with_grad
+        P = self.p
+        n_layers = len(self.acts)
+        tapped = set(self.taps)
+        # the deepest layer receives gradient from its tap only
+        last = n_layers - 1
+        self.grads[last].zero_()
+        scatter(last)
+        # walk the plan backwards; grads[li] always holds the ReLU-masked gradient of layer li's output
+        for step in reversed(self.plan):
+            if step[0] == 'pool':
+                _, pi, src_layer = step
+                _ops.maxpool2_bwd(self.acts[src_layer], self.gpools[pi], out=self.grads[src_layer])
+                if src_layer in tapped:
+                    scatter(src_layer)
+            else:
+                _, li, src = step
+                L = P.layers[li]
+                kind, si = src
+                if kind == 'img':
+                    _ops.conv3x3_c3_dgrad(self.grads[li], L["w_bwd"], self.gimg, accumulate=False, std=P.std)
+                    scatter(-1)
+                elif kind == 'conv':
+                    _ops.conv3x3_dgrad(self.grads[li], L["w_bwd"], L["cin"], act_in=self.acts[si], out=self.grads[si])
+                    if si in tapped:
+                        scatter(si)
+                else:
+                    _ops.conv3x3_dgrad(self.grads[li], L["w_bwd"], L["cin"], act_in=None, out=self.gpools[si])
+        return self.gimg
+
+
+class _VGGFn(torch.autograd.Function):
+    """autograd bridge for the public `VGG.__call__`: taps = f(img), d(img) from d(taps)."""
+
+    @staticmethod
+    def forward(ctx, img, vgg):
+        h, w = int(img.shape[1]), int(img.shape[2])
+        trunk = VGGTrunk(vgg.params, h, w, with_grad=img.requires_grad)
+        taps = trunk.forward(img.detach().contiguous())
+        ctx.trunk = trunk
+        return tuple(taps)
+
+    @staticmethod
+    def backward(ctx, *gtaps):
+        trunk = ctx.trunk
+
+        def scatter(li):
+            if li < 0:
+                return
+            k = trunk.taps.index(li)
+            g = gtaps[k]
+            if g is not None:
+                # incoming gradient is w.r.t. the post-ReLU tap: apply the mask here
+                trunk.grads[li].add_(g.contiguous() * (trunk.acts[li] > 0))
+        gimg = trunk.backward(scatter)
+        return gimg.clone(), None
+
+
+class VGG:
+    """feature extractor.  (reference: nn/model.py:17-55)"""
+
+    def __init__(self, layers: Optional[list] = None, vgg_type: str = '16', use_keras_weight: bool = False,
+                 name: Optional[str] = None, weights=None, seed: int = 0, device: str = "cuda"):
+        vgg_type = str(vgg_type)
+        assert vgg_type in ['16', '19']
+        self.name = name
+        if weights is None:
+            w = synthetic_weights(vgg_type, seed)
+        elif isinstance(weights, str):
+            w = load_weights(weights, vgg_type)
+        else:
+            w = list(weights)
+        self.params = VGGParams(w, vgg_type, layers or _STROTSS_DEFAULTS, device, use_keras_weight)
+        self.mean = torch.tensor(self.params.mean, dtype=torch.float32, device=device).view(1, 1, 1, -1)
+        self.std = torch.tensor(self.params.std, dtype=torch.float32, device=device).view(1, 1, 1, -1)
+
+    def preprocess(self, inputs: torch.Tensor) -> torch.Tensor:
+        # exposed for API parity; __call__ fuses it into the first conv kernel
+        return (inputs - self.mean) / self.std
+
+    def __call__(self, inputs: torch.Tensor) -> List[torch.Tensor]:
+        if inputs.dim() != 4 or inputs.shape[0] != 1 or inputs.shape[-1] != 3:
+            raise ValueError(f"expected a (1,H,W,3) image, got {tuple(inputs.shape)}")
+        if inputs.requires_grad:
+            return list(_VGGFn.apply(inputs, self))
+        trunk = VGGTrunk(self.params, int(inputs.shape[1]), int(inputs.shape[2]), with_grad=False)
+        return [t for t in trunk.forward(inputs.contiguous())]

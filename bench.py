@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""bench.py -- optimisation steps/sec of the STROTSS inner loop on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (run_strotss.py:131-148: fold -> VGG16 -> hypercolumn
+sampling -> self-similarity / moment / REMD / palette losses -> backward -> RMSprop) at the
+1024x1024 scale of a synthetic 1024-px content/style pair with 1024 samples of D = 2179 -- the
+configuration BASELINE.json's metric is quoted on.  Inputs (images, frozen weights, style
+statistics, the index stream) are resident in HBM before the timed region; fp32 throughout (the
+reference's dtype; the MFMA used is the exact-f32 one).  With N > 1 every rank optimises its own
+pair (replicas, no collective on the data path) and `value` is the sum.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      : the dominant kernel (3x3 conv implicit GEMM on the fp32 MFMA): algorithmic FLOP of
+                  all conv launches of one step / their summed HIP-event time, vs the 157.3 TFLOP/s
+                  dense f32 MFMA peak (MI355X_MICROARCH.md);
+  roofline_pairwise : the cosine cost-matrix GEMM (N x N x D) the metric names, same method;
+  cpu_baseline  : the oracle (oracle/strotss_oracle.py, fp32 torch-CPU restatement of the
+                  reference) timed on the host cores on a bounded sample of the same workload;
+  pyramid       : steps/s at every scale 64..1024 and the projected optimisation wall-clock of the
+                  full 5-scale x 200-step run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "strotss-tensorflow_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+F32_MFMA_PEAK_TFLOPS = 157.3
+SAMPLES = 1024
+D = 2179
+
+
+def synth_image(h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(1, h, w, 3, generator=g, dtype=torch.float32)
+    return torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), 5, 1, 2).permute(0, 2, 3, 1).contiguous()
+
+
+def conv_flops(params, h, w):
+    """algorithmic FLOP of one trunk forward (= one data-gradient pass) at (h, w)."""
+    total, ch, cw = 0.0, h, w
+    for it in params.cfg:
+        if it == 'pool':
+            ch, cw = ch // 2, cw // 2
+        else:
+            total += 2.0 * 9 * it[1] * it[2] * ch * cw
+    return total
+
+
+def build_engine(params, scale, dev, seed, sample_size=SAMPLES):
+    from nn import _ops, engine, strotss_utils as SU
+    content = synth_image(scale, scale, 100 + seed).to(dev)
+    style = synth_image(scale, scale, 200 + seed).to(dev)
+    rng = np.random.default_rng(seed)
+    cfeat = engine.extract_features(params, content)
+    sfeat = engine.extract_features(params, style)
+    s_idx = torch.from_numpy(SU.make_indices_np(scale, scale, False, sample_size, rng)).to(dev)
+    feats = _ops.hypercol_gather(sfeat, s_idx, False)
+    target = engine.StyleTarget.build(feats, int(s_idx.shape[0]), D)
+    del sfeat
+    init = SU.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
+    alpha = 1.0            # alpha at the 5th scale of the schedule 16, 8, 4, 2, 1
+    eng = engine.StepEngine(params, cfeat, [target], init, alpha, 2.0 + alpha + 1.0 / max(alpha, 1.0), 1e-3,
+                            sample_size=sample_size)
+    return eng, rng
+
+
+def index_stream(scale, count, rng, dev, sample_size=SAMPLES):
+    from nn import strotss_utils as SU
+    arr = np.stack([SU.make_indices_np(scale, scale, True, sample_size, rng) for _ in range(count)])
+    return torch.from_numpy(arr).to(dev)
+
+
+def run_steps(eng, idx, first, count):
+    for i in range(first, first + count):
+        eng.step([idx[i % idx.shape[0]]])
+
+
+def time_kernel_families(eng, idx, steps):
+    """HIP-event time of every conv launch and of the loss entry points over `steps` steps, on the
+    stream the kernels are launched on (torch's current stream)."""
+    from nn import _ops
+    rec = []
+
+    def wrap(name):
+        orig = getattr(_ops, name)
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            rec.append((name, e0, e1))
+            return r
+        setattr(_ops, name, timed)
+        return orig
+    names = ["conv3x3_relu_fwd", "conv3x3_dgrad", "selfsim_fwd_bwd", "remd_cos_fwd_bwd", "moment_fwd_bwd",
+             "palette_remd_fwd_bwd", "hypercol_scatter", "maxpool2_bwd", "maxpool2_fwd", "conv3x3_c3_fwd",
+             "conv3x3_c3_dgrad", "rmsprop_step", "resize_bilinear", "resize_bilinear_adjoint"]
+    origs = {n: wrap(n) for n in names}
+    try:
+        run_steps(eng, idx, 0, steps)
+        torch.cuda.synchronize()
+    finally:
+        for n, o in origs.items():
+            setattr(_ops, n, o)
+    out = {}
+    for name, e0, e1 in rec:
+        t, c = out.get(name, (0.0, 0))
+        out[name] = (t + e0.elapsed_time(e1), c + 1)
+    return {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in out.items()}
+
+
+def pairwise_roofline(dev, iters=50):
+    """The N x N x D cosine cost matrix (losses.py:12-15) on its own: algorithmic 2*N*N*D FLOP."""
+    from nn import _ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.zeros(SAMPLES, _ops.pad32(D)); x[:, :D] = torch.relu(torch.randn(SAMPLES, D, generator=g))
+    x = x.to(dev)
+    r = _ops.row_inv_norm(x, SAMPLES)
+    for _ in range(5):
+        _ops.cosine_distance(x, r, SAMPLES, x, r, SAMPLES)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        _ops.cosine_distance(x, r, SAMPLES, x, r, SAMPLES)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * SAMPLES * SAMPLES * D / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_kernel<64,64,KC,KC,EpiCosDist> (cosine cost matrix 1024x1024x2179)", "bound": "mfma",
+            "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
+
+
+def cpu_baseline(scale, budget_s=25.0):
+    """fp32 torch-CPU oracle (the restatement of the reference) on the same synthetic workload."""
+    from oracle import strotss_oracle as O
+    from nn.model import synthetic_weights
+    threads = int(os.environ.get("STROTSS_CPU_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    weights = synthetic_weights('16', 0)
+    vgg = O.VGG(weights, dtype=torch.float32)
+    content, style = synth_image(scale, scale, 100), synth_image(scale, scale, 200)
+    rng = np.random.default_rng(0)
+    with torch.no_grad():
+        cf = [content] + vgg(content)
+        sf = [style] + vgg(style)
+        ss = O.sample_features(sf, O.make_indices(scale, scale, False, SAMPLES, rng), False)
+    del sf
+    init = O.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
+    variables = [v.clone().requires_grad_(True) for v in O.make_laplacian_pyramid(init)]
+    rms = [torch.zeros_like(v) for v in variables]
+    alpha, denom = 1.0, 4.0
+    def one_step():
+        idx = O.make_indices(scale, scale, True, SAMPLES, rng)
+        t0 = time.perf_counter()
+        res = O.train_step(variables, vgg, cf, ss, idx, alpha, denom)
+        with torch.no_grad():
+            for v, r, g in zip(variables, rms, res["grads"]):
+                O.rmsprop_update(v, r, g, 1e-3)
+        return time.perf_counter() - t0
+
+    warm = one_step()
+    if warm > budget_s / 2:            # one step already eats the budget: report it (no warm-up)
+        timed, t_total, note = 1, warm, "no warm-up"
+    else:
+        timed, t_total, note = 0, 0.0, "after 1 warm-up"
+        while timed < 5 and (timed == 0 or t_total + t_total / timed <= budget_s):
+            t_total += one_step()
+            timed += 1
+    return {"value": round(timed / t_total, 5), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{timed} step(s) of the {scale}x{scale} scale (1024 samples) {note}, fp32 torch-CPU "
+                      f"oracle with {threads} threads (the reference pins TF to 1 thread, nn/rand.py:16-17)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pyramid", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from nn.model import VGGParams, synthetic_weights
+    params = VGGParams(synthetic_weights('16', 0), '16', None, dev)
+    S = args.scale
+    eng, rng = build_engine(params, S, dev, seed=rank)
+    idx = index_stream(S, max(8, min(64, args.steps + args.warmup)), rng, dev)
+
+    run_steps(eng, idx, 0, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(eng, idx, args.warmup, args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = eng.losses()
+
+    out = None
+    if rank == 0:
+        n_gpus = world
+        value = n_gpus * args.steps / elapsed
+        out = {"metric": "optimisation_steps_per_sec_1024px_pair", "value": round(value, 3), "unit": "steps/s",
+               "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{S}px content/style pair, {S}x{S} scale of the coarse-to-fine pyramid, "
+                                      f"{SAMPLES} samples x D={D}, VGG16 (seeded He-normal weights), "
+                                      f"RMSprop pixel update", "scale_px": S, "samples": SAMPLES,
+                          "parallelism": "replicas (one pair per GPU)" if n_gpus > 1 else "single GPU"},
+               "loss_after": round(losses["loss"], 5)}
+        # ---- per-kernel-family HIP-event timing (separate, untimed pass)
+        fam = time_kernel_families(eng, idx, 3)
+        conv_ms = fam["conv3x3_relu_fwd"]["ms_per_step"] + fam["conv3x3_dgrad"]["ms_per_step"]
+        conv_launches = fam["conv3x3_relu_fwd"]["launches_per_step"] + fam["conv3x3_dgrad"]["launches_per_step"]
+        c3 = 2.0 * 9 * 3 * 64 * S * S
+        algo = 2.0 * (conv_flops(params, S, S) - c3)       # MFMA conv launches: fwd + dgrad, first layer excluded
+        tf = algo / (conv_ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "conv3x3_mfma_kernel (3x3 conv implicit GEMM, fwd + dgrad, all launches of a step)",
+                           "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "algorithmic_gflop_per_step": round(algo / 1e9, 1), "launches_per_step": conv_launches,
+                           "avg_launch_ms": round(conv_ms / conv_launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
+        out["roofline_pairwise"] = pairwise_roofline(dev)
+        out["kernel_families_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(fam.items())}
+    if rank == 0 and not args.no_pyramid and world == 1:
+        del eng
+        torch.cuda.empty_cache()
+        pyr, total = {}, 0.0
+        for s in (64, 128, 256, 512):
+            e, r = build_engine(params, s, dev, seed=0)
+            ix = index_stream(s, 16, r, dev)
+            n = 30 if s <= 256 else 15
+            run_steps(e, ix, 0, 3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(e, ix, 3, n)
+            torch.cuda.synchronize()
+            sps = n / (time.perf_counter() - t1)
+            pyr[str(s)] = round(sps, 2)
+            total += 200.0 / sps
+            del e
+        if S == 1024:
+            pyr["1024"] = round(out["value"], 2)
+            total += 200.0 / out["value"]
+            out["pyramid"] = {"steps_per_sec_by_scale": pyr,
+                              "projected_optimisation_wall_clock_s_5x200": round(total, 2)}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(S)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

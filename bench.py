@@ -225,17 +225,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from nn import parallel
+    value, elapsed = parallel.aggregate_throughput(args.steps, time.perf_counter() - t0, device=dev)
     losses = eng.losses()
 
     out = None
     if rank == 0:
         n_gpus = world
-        value = n_gpus * args.steps / elapsed
         out = {"metric": "optimisation_steps_per_sec_1024px_pair", "value": round(value, 3), "unit": "steps/s",
                "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",

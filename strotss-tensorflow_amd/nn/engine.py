@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import _hip, _ops
+from . import _hip, _ops, parallel
 from .model import VGGParams, VGGTrunk
 
 
@@ -99,12 +99,8 @@ class StepEngine:
         self._layer_to_map[-1] = 0
         # region sharding
         self.group = dist_group
-        if dist_group is not None:
-            import torch.distributed as dist
-            self.rank, self.world = dist.get_rank(dist_group), dist.get_world_size(dist_group)
-        else:
-            self.rank, self.world = 0, 1
-        self.my_regions = list(range(self.rank, self.R, self.world))
+        self.rank, self.world = parallel.world_info(dist_group) if dist_group is not None else (0, 1)
+        self.my_regions = parallel.regions_for_rank(self.R, self.rank, self.world)
         self._idx: List[Optional[torch.Tensor]] = [None] * self.R
         self.steps_done = 0
 
@@ -146,6 +142,8 @@ class StepEngine:
     def forward_backward(self, indices: Sequence[torch.Tensor]) -> None:
         """train_step (run_strotss.py:131-142 / 104-125): fills self.gvars and self.scalars."""
         assert len(indices) == self.R
+        if self.world > 1:
+            self.scalars.zero_()          # regions owned by other ranks arrive through the all-reduce
         img = self.fold_forward()
         self.trunk.forward(img)
         for r in self.my_regions:
@@ -161,9 +159,8 @@ class StepEngine:
         else:
             gimg = self.trunk.gimg.zero_()
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(gimg, group=self.group)          # one RCCL all-reduce on the pixel gradient
-            dist.all_reduce(self.scalars, group=self.group)   # (tiny) so every rank can log
+            parallel.allreduce_sum_(gimg, self.group)          # one RCCL all-reduce on the pixel gradient
+            parallel.allreduce_sum_(self.scalars, self.group)   # (tiny) so every rank can log
         # adjoint of the fold: gvars[k] = up^T(gvars[k-1])
         for k in range(1, len(self.variables)):
             hk, wk = self.sizes[k]

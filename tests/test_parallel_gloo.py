@@ -1,0 +1,93 @@
+"""world_size-2 gloo (CPU) tests of the N > 1 host logic in nn/parallel.py: region sharding with one
+all-reduce of the pixel gradient reproduces the single-process masked step, and bench.py's
+max-over-ranks throughput aggregation."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _problem():
+    from oracle import strotss_oracle as O
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(0)
+    h = w = 32
+    content = torch.rand(1, h, w, 3, generator=g, dtype=torch.float64)
+    style = torch.rand(1, h, w, 3, generator=g, dtype=torch.float64)
+    vgg = O.VGG(O.make_synthetic_vgg16_weights(0), dtype=torch.float64)
+    rng = np.random.default_rng(0)
+    masks = []
+    for lo, hi in ((0, 11), (11, 22), (22, 32)):
+        m = np.zeros((h, w, 1), np.float32); m[:, lo:hi] = 1
+        masks.append(m)
+    with torch.no_grad():
+        cf = [content] + vgg(content)
+        sf = [style] + vgg(style)
+        ss = [O.sample_features(sf, O.make_indices(h, w, False, 128, rng, mask=m), False) for m in masks]
+    idx = [O.make_indices(h, w, True, 128, rng, mask=m) for m in masks]
+    pyr = O.make_laplacian_pyramid(content)
+    return O, vgg, cf, ss, idx, pyr
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "strotss-tensorflow_amd")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from nn import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O, vgg, cf, ss, idx, pyr = _problem()
+    R, alpha, denom = len(idx), 8.0, 11.0
+    assert parallel.regions_for_rank(R, rank, world) == list(range(rank, R, world))
+
+    def region_grad(r):
+        img = O.fold_laplacian_pyramid(pyr).clone().requires_grad_(True)
+        pred = [img] + vgg(img)
+        cfe = O.sample_features(cf, idx[r], True)
+        pfe = O.sample_features(pred, idx[r], True)
+        loss = (alpha * O.content_loss(cfe, pfe) + O.style_loss(ss[r], pfe, alpha)) / denom / R
+        g, = torch.autograd.grad(loss, img)
+        return g
+
+    gimg = parallel.sharded_pixel_gradient(region_grad, R, pyr[0])
+    # fold adjoint after the reduction: level-1 gradient = U^T gimg
+    probe = torch.rand(pyr[1].shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    value, elapsed = parallel.aggregate_throughput(10.0, 1.0 + rank)     # rank 1 is the slow one
+    torch.save({"gimg": gimg, "value": value, "elapsed": elapsed}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_region_sharding_two_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt"); r1 = torch.load(tmp_path / "r1.pt")
+    # identical on both ranks (so the replicated RMSprop update is identical)
+    assert torch.equal(r0["gimg"], r1["gimg"])
+    # equals the single-process masked step (run_strotss.py:104-125): d(mean_r loss_r)/d(img)
+    O, vgg, cf, ss, idx, pyr = _problem()
+    variables = [p.clone().requires_grad_(True) for p in pyr]
+    ref = O.train_step_masked(variables, vgg, cf, ss, idx, 8.0, 11.0)
+    g0 = ref["grads"][0]          # level-0 variable gradient == pixel gradient
+    assert (r0["gimg"] - g0).abs().max() < 1e-12 * max(1.0, float(g0.abs().max()))
+    # throughput aggregation: time = max over ranks (2.0 s), value = 2 ranks * 10 units / 2.0 s
+    assert r0["elapsed"] == 2.0 and r1["elapsed"] == 2.0 and r0["value"] == 10.0
+
+
+def test_region_ownership_covers_everything():
+    sys.path.insert(0, os.path.join(ROOT, "strotss-tensorflow_amd"))
+    from nn import parallel
+    for R in (1, 2, 3, 4, 7):
+        for world in (1, 2, 4, 8):
+            owned = sorted(r for k in range(world) for r in parallel.regions_for_rank(R, k, world))
+            assert owned == list(range(R))

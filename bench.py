@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--scale", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,6 +214,8 @@ def main():
     S = args.scale
     eng, rng = build_engine(params, S, dev, seed=rank)
     idx = index_stream(S, max(8, min(64, args.steps + args.warmup)), rng, dev)
+    if not args.no_graph:
+        eng.capture_graph([idx[0]])
 
     run_steps(eng, idx, 0, args.warmup)
     torch.cuda.synchronize()
@@ -240,8 +243,9 @@ def main():
                                       f"{SAMPLES} samples x D={D}, VGG16 (seeded He-normal weights), "
                                       f"RMSprop pixel update", "scale_px": S, "samples": SAMPLES,
                           "parallelism": "replicas (one pair per GPU)" if n_gpus > 1 else "single GPU"},
-               "loss_after": round(losses["loss"], 5)}
+               "loss_after": round(losses["loss"], 5), "launch_mode": "eager" if args.no_graph else "hipGraph"}
         # ---- per-kernel-family HIP-event timing (separate, untimed pass)
+        eng._graph = None                         # per-launch events need eager launches
         fam = time_kernel_families(eng, idx, 3)
         conv_ms = fam["conv3x3_relu_fwd"]["ms_per_step"] + fam["conv3x3_dgrad"]["ms_per_step"]
         conv_launches = fam["conv3x3_relu_fwd"]["launches_per_step"] + fam["conv3x3_dgrad"]["launches_per_step"]
@@ -262,6 +266,8 @@ def main():
         for s in (64, 128, 256, 512):
             e, r = build_engine(params, s, dev, seed=0)
             ix = index_stream(s, 16, r, dev)
+            if not args.no_graph:
+                e.capture_graph([ix[0]])
             n = 30 if s <= 256 else 15
             run_steps(e, ix, 0, 3)
             torch.cuda.synchronize()

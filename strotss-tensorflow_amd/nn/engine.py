@@ -103,6 +103,9 @@ class StepEngine:
         self.my_regions = parallel.regions_for_rank(self.R, self.rank, self.world)
         self._idx: List[Optional[torch.Tensor]] = [None] * self.R
         self.steps_done = 0
+        self._graph = None
+        self._graph_idx: List[torch.Tensor] = []
+        self._graph_n: List[int] = []
 
     # ------------------------------------------------------------------ pieces of the step
     def fold_forward(self) -> torch.Tensor:
@@ -171,9 +174,40 @@ class StepEngine:
         _ops.rmsprop_step(self.variables, self.rms, self.gvars, self.lr, self.rho, self.eps)
 
     def step(self, indices: Sequence[torch.Tensor]) -> None:
-        self.forward_backward(indices)
-        self.apply_gradients()
+        if self._graph is not None and all(int(i.shape[0]) == self._graph_n[r] for r, i in enumerate(indices)):
+            for dst, src in zip(self._graph_idx, indices):
+                dst.copy_(src, non_blocking=True)
+            self._graph.replay()
+        else:
+            self.forward_backward(indices)
+            self.apply_gradients()
         self.steps_done += 1
+
+    def capture_graph(self, example_indices: Sequence[torch.Tensor]) -> None:
+        """Capture forward_backward + apply_gradients into ONE hipGraph (the ~100 launches of a step
+        replay as one submission; the 64-256 px scales are otherwise bound by host launch rate).  Index
+        sets are copied into static buffers before each replay; a step whose index counts differ from
+        the captured ones runs eagerly.  The captured step does not advance the optimisation: the
+        variables / RMSprop slots are snapshotted around the warm-up and capture passes."""
+        if self.world > 1:
+            return                      # collectives stay outside graphs in this build
+        snap = [t.clone() for t in self.variables + self.rms]
+        self._graph_idx = [i.clone() for i in example_indices]
+        self._graph_n = [int(i.shape[0]) for i in example_indices]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # warm-up on the side stream (workspace allocation)
+            self.forward_backward(self._graph_idx)
+            self.apply_gradients()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward_backward(self._graph_idx)
+            self.apply_gradients()
+        for t, s0 in zip(self.variables + self.rms, snap):
+            t.copy_(s0)
+        self._graph = g
 
     # ------------------------------------------------------------------ read-outs (host sync)
     def losses(self) -> dict:

@@ -121,10 +121,13 @@ def run(args: argparse.Namespace):
         h, w = eng.h, eng.w
         region_masks = [strotss.mask_at_scale(m, h, w) if m is not None else None for m in content_masks]
 
+        use_graph = not getattr(args, "no_graph", False)
         with tqdm(range(args.max_iter)) as pbar:
             for it in pbar:
                 idx = [torch.from_numpy(strotss.make_indices_np(h, w, True, sample_size, rand.index_rng, mk)).to(dev)
                        for mk in region_masks]
+                if it == 0 and use_graph:
+                    eng.capture_graph(idx)
                 eng.step(idx)
                 if (it + 1) % log_every == 0 or it + 1 == args.max_iter:
                     result = eng.losses()
@@ -166,6 +169,7 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--weights", type=str, default=None)
     parser.add_argument("--log_every", type=int, default=10)
+    parser.add_argument("--no_graph", action="store_true", help="launch kernels eagerly instead of one hipGraph per step")
     return parser
 
 

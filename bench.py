@@ -105,7 +105,7 @@ def time_kernel_families(eng, idx, steps):
             return r
         setattr(_ops, name, timed)
         return orig
-    names = ["conv3x3_relu_fwd", "conv3x3_dgrad", "selfsim_fwd_bwd", "remd_cos_fwd_bwd", "moment_fwd_bwd",
+    names = ["conv3x3_relu_fwd", "conv3x3_dgrad", "conv3x3_winograd_fwd", "conv3x3_winograd_dgrad", "selfsim_fwd_bwd", "remd_cos_fwd_bwd", "moment_fwd_bwd",
              "palette_remd_fwd_bwd", "hypercol_scatter", "maxpool2_bwd", "maxpool2_fwd", "conv3x3_c3_fwd",
              "conv3x3_c3_dgrad", "rmsprop_step", "resize_bilinear", "resize_bilinear_adjoint"]
     origs = {n: wrap(n) for n in names}
@@ -247,15 +247,24 @@ def main():
         # ---- per-kernel-family HIP-event timing (separate, untimed pass)
         eng._graph = None                         # per-launch events need eager launches
         fam = time_kernel_families(eng, idx, 3)
-        conv_ms = fam["conv3x3_relu_fwd"]["ms_per_step"] + fam["conv3x3_dgrad"]["ms_per_step"]
-        conv_launches = fam["conv3x3_relu_fwd"]["launches_per_step"] + fam["conv3x3_dgrad"]["launches_per_step"]
+        conv_names = [n for n in ("conv3x3_relu_fwd", "conv3x3_dgrad", "conv3x3_winograd_fwd", "conv3x3_winograd_dgrad")
+                      if n in fam]
+        conv_ms = sum(fam[n]["ms_per_step"] for n in conv_names)
+        conv_launches = sum(fam[n]["launches_per_step"] for n in conv_names)
         c3 = 2.0 * 9 * 3 * 64 * S * S
-        algo = 2.0 * (conv_flops(params, S, S) - c3)       # MFMA conv launches: fwd + dgrad, first layer excluded
+        algo = 2.0 * (conv_flops(params, S, S) - c3)       # direct-form FLOP of the 12 MFMA conv layers, fwd + dgrad
+        executed = 2.0 * sum(2.0 * (4 if "u_fwd" in L else 9) * L["cin"] * L["cout"] * a.shape[1] * a.shape[2]
+                             for L, a in zip(params.layers, eng.trunk.acts) if L["cin"] != 3)
         tf = algo / (conv_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "conv3x3_mfma_kernel (3x3 conv implicit GEMM, fwd + dgrad, all launches of a step)",
+        out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA: conv3x3_mfma_v3_kernel (direct implicit GEMM, Cin=64 "
+                                     "layers) + gemm_kc_pipe_kernel (16 Winograd F(2x2,3x3) GEMMs, Cin>=128 layers) "
+                                     "incl. their transform kernels; fwd + dgrad, all launches of a step",
                            "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                           "algorithmic_gflop_per_step": round(algo / 1e9, 1), "launches_per_step": conv_launches,
+                           "algorithmic_gflop_per_step": round(algo / 1e9, 1),
+                           "mfma_executed_gflop_per_step": round(executed / 1e9, 1),
+                           "mfma_executed_tflops": round(executed / (conv_ms * 1e-3) / 1e12, 2),
+                           "launches_per_step": conv_launches,
                            "avg_launch_ms": round(conv_ms / conv_launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
         out["roofline_pairwise"] = pairwise_roofline(dev)
         out["kernel_families_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(fam.items())}

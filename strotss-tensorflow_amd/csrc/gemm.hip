@@ -29,14 +29,16 @@ __device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, int l
 // ---------------------------------------------------------------- epilogues
 struct EpiCosDist {  // C = 1 - acc * (ra[i]*rb[j])      (losses.py:12-15)
   const float* ra; const float* rb; float* C; int ldc; int M, N;
+  __device__ __forceinline__ void set_batch(int) {}
   __device__ __forceinline__ float apply(int r, int c, float v) const {
     if (r < M && c < N) C[(size_t)r * ldc + c] = 1.0f - v * (ra[r] * rb[c]);
     return 0.f;
   }
   __device__ __forceinline__ void finish(float*, float) const {}
 };
-struct EpiScaleStore {  // C = alpha * acc
-  float* C; int ldc; int M, N; float alpha;
+struct EpiScaleStore {  // C = alpha * acc   (batched: C += z * strideC)
+  float* C; int ldc; int M, N; float alpha; long long strideC;
+  __device__ __forceinline__ void set_batch(int z) { C += (long long)z * strideC; }
   __device__ __forceinline__ float apply(int r, int c, float v) const {
     if (r < M && c < N) C[(size_t)r * ldc + c] = alpha * v;
     return 0.f;
@@ -45,6 +47,7 @@ struct EpiScaleStore {  // C = alpha * acc
 };
 struct EpiAxpbyBias {  // C = alpha*acc + C + bias[c]
   float* C; int ldc; int M, N; float alpha; const float* bias; float bias_scale;
+  __device__ __forceinline__ void set_batch(int) {}
   __device__ __forceinline__ float apply(int r, int c, float v) const {
     if (r < M && c < N) {
       float* p = &C[(size_t)r * ldc + c];
@@ -108,6 +111,145 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
   epi.finish(lds, local);
 }
 
+// Pipelined K-contiguous x K-contiguous GEMM (same structure as conv3x3_mfma_v3_kernel in conv.hip):
+// double-buffered LDS, ONE barrier per K-step placed before the last 8 MFMAs, register
+// double-buffered fragments, staging (LDS writes of tile s+1 / global loads of tile s+2) pinned
+// between the MFMA groups.  Batched over blockIdx.z (strideA/strideB elements, epi.set_batch(z)).
+template <int BM, int BN, class Epi>
+__global__ __launch_bounds__(256) void gemm_kc_pipe_kernel(const float* __restrict__ A, int lda, int M,
+                                                           long long strideA, const float* __restrict__ B,
+                                                           int ldb, int N, long long strideB, int K, Epi epi) {
+  constexpr int A_FL = OperandLds<BM>::kc_floats, B_FL = OperandLds<BN>::kc_floats;
+  constexpr int TM = BM / 64, TN = BN / 64, NA = BM / 32, NB = BN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FL + B_FL)];
+  A += (long long)blockIdx.z * strideA;
+  B += (long long)blockIdx.z * strideB;
+  epi.set_batch(blockIdx.z);
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int t = threadIdx.x, c4 = t & 7, r0 = t >> 3;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+
+  size_t abase[NA], bbase[NB];
+  unsigned aok = 0, bok = 0;      // rows inside the matrix (others are staged as zeros)
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = m0 + r0 + 32 * i;
+    aok |= (unsigned)(r < M) << i;
+    abase[i] = (size_t)min(r, M - 1) * lda + c4 * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = n0 + r0 + 32 * i;
+    bok |= (unsigned)(r < N) << i;
+    bbase[i] = (size_t)min(r, N - 1) * ldb + c4 * 4;
+  }
+  const int steps = K >> 5;
+  int k0 = 0;                      // K offset of the NEXT tile to load (wraps past the end)
+  f32x4 ra[NA], rb[NB];
+  auto load_a = [&](int i) { ra[i] = *reinterpret_cast<const f32x4*>(A + abase[i] + k0); };
+  auto load_b = [&](int i) { rb[i] = *reinterpret_cast<const f32x4*>(B + bbase[i] + k0); };
+  auto advance = [&]() { k0 += 32; if (k0 >= K) k0 = 0; };
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto store_a = [&](float* buf, int i) {
+    *reinterpret_cast<f32x4*>(&buf[(r0 + 32 * i) * KC_LD + c4 * 4]) = ((aok >> i) & 1u) ? ra[i] : z4;
+  };
+  auto store_b = [&](float* buf, int i) {
+    *reinterpret_cast<f32x4*>(&buf[A_FL + (r0 + 32 * i) * KC_LD + c4 * 4]) = ((bok >> i) & 1u) ? rb[i] : z4;
+  };
+
+  f32x16 acc[TM][TN];
+  acc_zero<BM, BN>(acc);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) load_a(i);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) load_b(i);
+  advance();
+#pragma unroll
+  for (int i = 0; i < NA; ++i) store_a(lds, i);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) store_b(lds, i);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) load_a(i);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) load_b(i);
+  advance();
+  __syncthreads();
+
+  const int arow = (wm * (BM / 2) + l31) * KC_LD + 4 * hh;
+  const int brow = A_FL + (wn * (BN / 2) + l31) * KC_LD + 4 * hh;
+  f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&lds[arow + i * 32 * KC_LD]);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&lds[brow + i * 32 * KC_LD]);
+  for (int s = 0; s < steps; ++s) {
+    const float* cur = lds + (s & 1) * (A_FL + B_FL);
+    float* nxt = lds + ((s + 1) & 1) * (A_FL + B_FL);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&cur[arow + i * 32 * KC_LD + 8 * (g + 1)]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          fb[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&cur[brow + i * 32 * KC_LD + 8 * (g + 1)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in_ = 0; in_ < TN; ++in_)
+            acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][im][j], fb[g & 1][in_][j], acc[im][in_], 0, 0, 0);
+        if (j == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = g; i < NA; i += 4) { store_a(nxt, i); load_a(i); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = g; i < NB; i += 4) { store_b(nxt, i); load_b(i); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (g == 3) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&nxt[arow + i * 32 * KC_LD]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&nxt[brow + i * 32 * KC_LD]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+    advance();
+  }
+  AccMap<BM, BN> map;
+  float local = 0.f;
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
+  __syncthreads();
+  epi.finish(lds, local);
+}
+
+template <int BM, int BN, class Epi>
+int launch_pipe(const float* A, int lda, int M, long long strideA, const float* B, int ldb, int N,
+                long long strideB, int K, int batch, Epi epi, hipStream_t s) {
+  dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
+  hipLaunchKernelGGL((gemm_kc_pipe_kernel<BM, BN, Epi>), grid, dim3(256), 0, s, A, lda, M, strideA, B, ldb, N,
+                     strideB, K, epi);
+  ST_LAUNCH_RET();
+}
+
 template <int BM, int BN, bool AKC, bool BKC, class Epi>
 int launch(const float* A, int lda, int M, const float* B, int ldb, int N, int K, Epi epi,
            hipStream_t s) {
@@ -123,12 +265,12 @@ int launch(const float* A, int lda, int M, const float* B, int ldb, int N, int K
 int st_cosine_distance(const float* x, const float* rx, int nx, const float* y, const float* ry, int ny,
                        int ld, float* C, int ldc, hipStream_t s) {
   EpiCosDist e{rx, ry, C, ldc, nx, ny};
-  return launch<64, 64, true, true>(x, ld, nx, y, ld, ny, ld, e, s);
+  return launch_pipe<64, 64>(x, ld, nx, 0, y, ld, ny, 0, ld, 1, e, s);
 }
 
 // C(M x N) = alpha * A^T A where A is (K x ld) row-major, rows [krows..) zero: covariance.
 int st_gram_tn(const float* A, int krows, int ld, float alpha, float* C, hipStream_t s) {
-  EpiScaleStore e{C, ld, ld, ld, alpha};
+  EpiScaleStore e{C, ld, ld, ld, alpha, 0};
   return launch<64, 64, false, false>(A, ld, ld, A, ld, ld, krows, e, s);
 }
 
@@ -143,7 +285,7 @@ int st_moment_fwd_gemm(const float* cy, int krows, int ld, const float* Sx, floa
 int st_moment_bwd_gemm(const float* cy, int n, int ld, const float* T, float alpha, const float* bias,
                        float bias_scale, float* dY, hipStream_t s) {
   EpiAxpbyBias e{dY, ld, n, ld, alpha, bias, bias_scale};
-  return launch<64, 64, true, true>(cy, ld, n, T, ld, ld, ld, e, s);
+  return launch_pipe<64, 64>(cy, ld, n, 0, T, ld, ld, 0, ld, 1, e, s);
 }
 
 // dX(n x ld) += g * r_i (Mq(n x kpad) @ X(kpad x ld) - xhat q)
@@ -151,4 +293,15 @@ int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, cons
                         int n, int ld, float g, float* dx, hipStream_t s) {
   EpiSelfsimBwd e{x, r, q, dx, ld, n, ld, g};
   return launch<64, 64, true, false>(Mq, ldm, n, x, ld, ld, kpad, e, s);
+}
+
+// Batched C[z] (M x N, ldc) = A[z] (M x K, lda) * B[z]^T (N x K, ldb): the 16 Winograd-domain GEMMs.
+int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
+                       float* C, int ldc, long long strideC, int M, int N, int K, int batch, hipStream_t s) {
+  EpiScaleStore e{C, ldc, M, N, 1.0f, strideC};
+  if ((long long)cdiv(M, 128) * cdiv(N, 128) * batch >= 512 && N % 128 == 0)
+    return launch_pipe<128, 128>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
+  if ((long long)cdiv(M, 128) * cdiv(N, 64) * batch >= 512)
+    return launch_pipe<128, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
+  return launch_pipe<64, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
 }

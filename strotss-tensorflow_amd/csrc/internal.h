@@ -13,6 +13,9 @@ int st_moment_bwd_gemm(const float* cy, int n, int ld, const float* T, float alp
 int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, const float* r, const float* q,
                         int n, int ld, float g, float* dx, hipStream_t s);
 
+int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
+                       float* C, int ldc, long long strideC, int M, int N, int K, int batch, hipStream_t s);
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Bump allocator over a caller-provided workspace (256-byte aligned slices).

@@ -1,0 +1,158 @@
+// Winograd F(2x2, 3x3) form of the VGG 3x3 convolutions (nn/model.py:44-48) for the deep layers,
+// where the f32 MFMA -- not HBM -- is the limit: 16 Winograd-domain GEMMs of (tiles x Cin)x(Cin x Cout)
+// do 4*HW*Cin*Cout MACs instead of the direct form's 9*HW*Cin*Cout (2.25x fewer).
+//
+//   V[p] = (B^T d B)[p]     input transform   (one 4x4 input patch per 2x2 output tile, p = 0..15)
+//   M[p] = V[p] U[p]^T      batched GEMM on the pipelined f32-MFMA kernel (gemm.hip)
+//   Y    = A^T M A          output transform + bias + ReLU (forward) or ReLU mask (data-gradient)
+//
+// U[p] = (G g G^T)[p] is pre-computed once per model on the host (frozen weights).  The two
+// transforms are streaming kernels (V and M are 4x the activation size; at the sizes used they
+// live in the 256 MiB Infinity Cache between producer and consumer).
+#include "internal.h"
+
+namespace {
+
+// V: (16, T, C) with T = ceil(H/2)*ceil(W/2); tile (ty,tx) reads input rows 2ty-1..2ty+2, cols 2tx-1..2tx+2
+__global__ __launch_bounds__(256) void winograd_in_kernel(const float* __restrict__ in, int H, int W, int C4,
+                                                          int TH, int TW, float* __restrict__ V) {
+  const size_t T = (size_t)TH * TW;
+  const size_t total = T * C4;
+  const f32x4* src = reinterpret_cast<const f32x4*>(in);
+  f32x4* dst = reinterpret_cast<f32x4*>(V);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C4);
+    const size_t tile = e / C4;
+    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+    f32x4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = 2 * ty - 1 + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int x = 2 * tx - 1 + q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && x >= 0 && x < W) v = src[((size_t)y * W + x) * C4 + c];
+        d[r][q] = v;
+      }
+    }
+    // t = B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
+    f32x4 tt[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      tt[0][q] = d[0][q] - d[2][q];
+      tt[1][q] = d[1][q] + d[2][q];
+      tt[2][q] = d[2][q] - d[1][q];
+      tt[3][q] = d[1][q] - d[3][q];
+    }
+    // V = t B : columns (t0-t2, t1+t2, t2-t1, t1-t3)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1],
+                  v3 = tt[r][1] - tt[r][3];
+      dst[((size_t)(r * 4 + 0) * T + tile) * C4 + c] = v0;
+      dst[((size_t)(r * 4 + 1) * T + tile) * C4 + c] = v1;
+      dst[((size_t)(r * 4 + 2) * T + tile) * C4 + c] = v2;
+      dst[((size_t)(r * 4 + 3) * T + tile) * C4 + c] = v3;
+    }
+  }
+}
+
+// Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]];  out = relu(Y + bias)  or  (mask > 0 ? Y : 0)
+__global__ __launch_bounds__(256) void winograd_out_kernel(const float* __restrict__ Mw, int H, int W, int C4,
+                                                           int TH, int TW, const float* __restrict__ bias,
+                                                           const float* __restrict__ mask, int relu,
+                                                           float* __restrict__ out) {
+  const size_t T = (size_t)TH * TW;
+  const size_t total = T * C4;
+  const f32x4* src = reinterpret_cast<const f32x4*>(Mw);
+  const f32x4* msk = reinterpret_cast<const f32x4*>(mask);
+  f32x4* dst = reinterpret_cast<f32x4*>(out);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C4);
+    const size_t tile = e / C4;
+    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+    f32x4 m[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) m[r][q] = src[((size_t)(r * 4 + q) * T + tile) * C4 + c];
+    f32x4 s[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s[0][q] = m[0][q] + m[1][q] + m[2][q];
+      s[1][q] = m[1][q] - m[2][q] - m[3][q];
+    }
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b = reinterpret_cast<const f32x4*>(bias)[c];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int y = 2 * ty + r;
+      if (y >= H) continue;
+      const f32x4 y0 = s[r][0] + s[r][1] + s[r][2] + b;
+      const f32x4 y1 = s[r][1] - s[r][2] - s[r][3] + b;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int x = 2 * tx + q;
+        if (x >= W) continue;
+        f32x4 v = q ? y1 : y0;
+        const size_t o = ((size_t)y * W + x) * C4 + c;
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (mask) {
+          const f32x4 k = msk[o];
+          v[0] = k[0] > 0.f ? v[0] : 0.f; v[1] = k[1] > 0.f ? v[1] : 0.f;
+          v[2] = k[2] > 0.f ? v[2] : 0.f; v[3] = k[3] > 0.f ? v[3] : 0.f;
+        }
+        dst[o] = v;
+      }
+    }
+  }
+}
+
+int winograd_run(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
+                 const float* mask, int relu, float* out, void* workspace, size_t workspace_bytes,
+                 hipStream_t st) {
+  const int TH = (h + 1) / 2, TW = (w + 1) / 2;
+  const size_t T = (size_t)TH * TW;
+  Workspace ws(workspace, workspace_bytes);
+  float* V = ws.take<float>(16 * T * cin);
+  float* Mw = ws.take<float>(16 * T * cout);
+  if (!ws.ok()) return STROTSS_EINVAL;
+  const size_t tin = T * (cin / 4), tout = T * (cout / 4);
+  hipLaunchKernelGGL(winograd_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
+                     h, w, cin / 4, TH, TW, V);
+  int rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
+                              (long long)T * cout, (int)T, cout, cin, 16, st);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(winograd_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
+                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out);
+  ST_LAUNCH_RET();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout) {
+  const size_t T = (size_t)((h + 1) / 2) * ((w + 1) / 2);
+  return ws_slice(16 * T * cin, sizeof(float)) + ws_slice(16 * T * cout, sizeof(float));
+}
+
+int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok, const float* bias,
+                                 int cout, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(in && u_pok && bias && out && workspace && h > 0 && w > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, STROTSS_EALIGN);
+  return winograd_run(in, h, w, cin, u_pok, bias, cout, nullptr, 1, out, workspace, workspace_bytes,
+                      (hipStream_t)stream);
+}
+
+int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik, int cin,
+                                   const float* act_in, float* gin, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  ST_CHECK_ARG(gout && u_pik && gin && workspace && h > 0 && w > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
+  return winograd_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
+                      (hipStream_t)stream);
+}
+
+}  // extern "C"

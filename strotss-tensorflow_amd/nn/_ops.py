@@ -96,6 +96,40 @@ def conv3x3_c3_dgrad(gout, w_tic, gimg=None, accumulate=False, std=None):
     return gimg
 
 
+def _wino_ws(h, w, cin, cout, device):
+    nb = _hip.lib().strotss_conv3x3_winograd_workspace_bytes(h, w, cin, cout)
+    return workspaces.get("winograd", nb, device), nb
+
+
+def conv3x3_winograd_fwd(x, u_pok, bias, out=None):
+    require(x, "conv input"); h, w, cin = hwc(x)
+    cout = bias.numel()
+    if out is None:
+        out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
+    ws, nb = _wino_ws(h, w, cin, cout, x.device)
+    check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(bias), cout, ptr(out),
+                                                  ptr(ws), nb, stream_ptr()), "conv3x3_winograd_fwd")
+    return out
+
+
+def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
+    require(gout, "conv grad"); h, w, cout = hwc(gout)
+    if out is None:
+        out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
+    ws, nb = _wino_ws(h, w, cout, cin, gout.device)
+    check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), cin, ptr(act_in), ptr(out),
+                                                    ptr(ws), nb, stream_ptr()), "conv3x3_winograd_dgrad")
+    return out
+
+
+def winograd_weights(g: torch.Tensor) -> torch.Tensor:
+    """g: (N, K, 3, 3) kernel as [out-channel][in-channel][r][q] (float64 on the host) ->
+    U (16, N, K) float32 with U[4*xi+nu] = (G g G^T)[xi, nu]."""
+    G = torch.tensor([[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]], dtype=torch.float64)
+    u = torch.einsum("ar,nkrq,bq->abnk", G, g.double(), G)
+    return u.reshape(16, g.shape[0], g.shape[1]).float().contiguous()
+
+
 def maxpool2_fwd(x, out=None):
     require(x, "pool input"); h, w, c = hwc(x)
     if out is None:

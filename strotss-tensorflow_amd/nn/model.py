@@ -12,6 +12,7 @@ The trunk is frozen (model.py:45): only the data gradient exists.
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -69,6 +70,19 @@ def load_weights(path: str, vgg_type: str = '16') -> List[Tuple[torch.Tensor, to
     return out
 
 
+def use_winograd(cin: int, cout: int) -> bool:
+    """Layers that run in Winograd F(2x2,3x3) form: Cin >= 128 (block2_conv2 and deeper), where the
+    f32 MFMA -- not HBM -- is the limit and the 4x larger transform-domain tensors are affordable
+    (measured on MI355X at 1024 px: 1.2x at 128->128 up to 2.0x at 512->512; a loss at Cin = 64).  STROTSS_WINOGRAD=0
+    disables it, =all forces it for every generic layer."""
+    mode = os.environ.get("STROTSS_WINOGRAD", "auto")
+    if mode == "0":
+        return False
+    if mode == "all":
+        return cin % 32 == 0 and cout % 64 == 0
+    return cin >= 128 and cin % 32 == 0 and cout % 64 == 0      # measured per layer: tools/conv_bench.py
+
+
 class VGGParams:
     """Frozen weights on the device in the layouts the kernels want (built once)."""
 
@@ -117,6 +131,10 @@ class VGGParams:
             else:
                 L["w_fwd"] = w.permute(0, 1, 3, 2).reshape(9, cout, cin).contiguous().to(device)   # (9,cout,cin)
                 L["w_bwd"] = w.flip(0, 1).reshape(9, cin, cout).contiguous().to(device)           # (9,cin,cout)
+                if use_winograd(cin, cout):
+                    # forward: g[co][ci][r][q] = W[r,q,ci,co]; dgrad: g'[ci][co][r][q] = W[2-r,2-q,ci,co]
+                    L["u_fwd"] = _ops.winograd_weights(w.permute(3, 2, 0, 1)).to(device)
+                    L["u_bwd"] = _ops.winograd_weights(w.flip(0, 1).permute(2, 3, 0, 1)).to(device)
             self.layers.append(L)
         self.device = device
 
@@ -183,6 +201,8 @@ class VGGTrunk:
                 x = self._src(src)
                 if L["cin"] == 3:
                     _ops.conv3x3_c3_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li], mean=P.mean, std=P.std)
+                elif "u_fwd" in L:
+                    _ops.conv3x3_winograd_fwd(x, L["u_fwd"], L["bias"], out=self.acts[li])
                 else:
                     _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
         return [self.acts[i] for i in self.taps]
@@ -211,11 +231,15 @@ class VGGTrunk:
                     _ops.conv3x3_c3_dgrad(self.grads[li], L["w_bwd"], self.gimg, accumulate=False, std=P.std)
                     scatter(-1)
                 elif kind == 'conv':
-                    _ops.conv3x3_dgrad(self.grads[li], L["w_bwd"], L["cin"], act_in=self.acts[si], out=self.grads[si])
+                    dgrad = _ops.conv3x3_winograd_dgrad if "u_bwd" in L else _ops.conv3x3_dgrad
+                    dgrad(self.grads[li], L["u_bwd"] if "u_bwd" in L else L["w_bwd"], L["cin"], act_in=self.acts[si],
+                          out=self.grads[si])
                     if si in tapped:
                         scatter(si)
                 else:
-                    _ops.conv3x3_dgrad(self.grads[li], L["w_bwd"], L["cin"], act_in=None, out=self.gpools[si])
+                    dgrad = _ops.conv3x3_winograd_dgrad if "u_bwd" in L else _ops.conv3x3_dgrad
+                    dgrad(self.grads[li], L["u_bwd"] if "u_bwd" in L else L["w_bwd"], L["cin"], act_in=None,
+                          out=self.gpools[si])
         return self.gimg
 
 

@@ -82,5 +82,7 @@ def test_trace_against_fixture():
         assert abs(got["loss"] - z["trace"][it, 0]) < 2e-2 * it * abs(z["trace"][it, 0]), (it, got["loss"], z["trace"][it, 0])
     out = eng.stylized()
     assert np.abs(out.cpu().numpy() - z["final"]).mean() < 0.03
-    u8 = SU.postprocess(out).cpu().numpy().astype(int)
-    assert np.abs(u8 - z["final_u8"].astype(int)).mean() < 8
+    # postprocess kernel on the FIXTURE's final float image == the fixture's uint8 (truncation boundary: +-1)
+    u8 = SU.postprocess(dev(z["final"])).cpu().numpy().astype(int)
+    d = np.abs(u8 - z["final_u8"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01

@@ -126,6 +126,31 @@ def test_conv_generic_fwd_and_dgrad(ops, cfg):
         assert rel_err(got, (xin.grad * (x > 0)).numpy()) < 3e-6
 
 
+@pytest.mark.parametrize("cfg", [(16, 24, 128, 256), (9, 7, 256, 256), (5, 3, 512, 512), (33, 20, 64, 64),
+                                 (1, 1, 128, 128), (2, 4, 256, 512)])
+def test_conv_winograd_fwd_and_dgrad(ops, cfg):
+    """Winograd F(2x2,3x3) entry points == the direct convolution (odd sizes exercise partial tiles)."""
+    h, w, cin, cout = cfg
+    g = torch.Generator().manual_seed(h * w + cin + 1)
+    x = torch.relu(torch.randn(1, h, w, cin, generator=g, dtype=torch.float64))
+    wt = torch.randn(3, 3, cin, cout, generator=g, dtype=torch.float64) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g, dtype=torch.float64) * 0.1
+    xin = x.clone().requires_grad_(True)
+    y = _conv_ref(xin, wt, b)
+    u_f = ops.winograd_weights(wt.permute(3, 2, 0, 1)).cuda()
+    got = ops.conv3x3_winograd_fwd(dev(x), u_f, dev(b)).cpu().numpy()
+    assert rel_err(got, y.detach().numpy()) < 1e-5
+    gy = torch.randn(1, h, w, cout, generator=g, dtype=torch.float64)
+    ypre = _conv_ref(xin, wt, b, relu=False)
+    (ypre * gy).sum().backward()
+    u_b = ops.winograd_weights(wt.flip(0, 1).permute(2, 3, 0, 1)).cuda()
+    if cin % 64 == 0:
+        got = ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin).cpu().numpy()
+        assert rel_err(got, xin.grad.numpy()) < 1e-5
+        got = ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin, act_in=dev(x)).cpu().numpy()
+        assert rel_err(got, (xin.grad * (x > 0)).numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("hwc", [(8, 12, 64), (9, 7, 128), (2, 2, 4), (33, 65, 64)])
 def test_maxpool(ops, hwc):
     h, w, c = hwc

@@ -32,11 +32,15 @@ def main():
         out = torch.empty(1, hw, hw, cout, device=dev)
         gin = torch.empty(1, hw, hw, cin, device=dev)
         flops = 2.0 * 9 * cin * cout * hw * hw
-        for kind in ("fwd", "dgrad"):
-            if kind == "dgrad" and cin % 64:
+        u = (torch.randn(16, cout, cin, generator=g) * 0.05).to(dev)
+        ub = (torch.randn(16, cin, cout, generator=g) * 0.05).to(dev)
+        for kind in ("fwd", "dgrad", "wfwd", "wdgrad"):
+            if kind.endswith("dgrad") and cin % 64:
                 continue
-            fn = (lambda: _ops.conv3x3_relu_fwd(x, w, b, out=out)) if kind == "fwd" else \
-                 (lambda: _ops.conv3x3_dgrad(gy, wb, cin, act_in=x, out=gin))
+            fn = {"fwd": lambda: _ops.conv3x3_relu_fwd(x, w, b, out=out),
+                  "dgrad": lambda: _ops.conv3x3_dgrad(gy, wb, cin, act_in=x, out=gin),
+                  "wfwd": lambda: _ops.conv3x3_winograd_fwd(x, u, b, out=out),
+                  "wdgrad": lambda: _ops.conv3x3_winograd_dgrad(gy, ub, cin, act_in=x, out=gin)}[kind]
             for _ in range(2):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,8 +51,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
-            tot_t += ms; tot_f += flops
-            print(f"{name:5s} {kind:5s} hw={hw:5d} cin={cin:4d} cout={cout:4d}  {ms*1e3:9.1f} us  {flops/ms/1e9:7.1f} TFLOP/s")
+            if not kind.startswith("w"):
+                tot_t += ms; tot_f += flops
+            print(f"{name:5s} {kind:6s} hw={hw:5d} cin={cin:4d} cout={cout:4d}  {ms*1e3:9.1f} us  {flops/ms/1e9:7.1f} TFLOP/s")
     if tot_t:
         print(f"total {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TFLOP/s")
 

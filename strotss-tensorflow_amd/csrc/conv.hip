@@ -6,7 +6,7 @@
 #include <stdlib.h>
 
 #include "internal.h"
-#include "mfma_tile.h"
+#include "mfma_pipe.h"
 
 namespace {
 
@@ -90,251 +90,95 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   }
 }
 
-// v2: double-buffered LDS, ONE barrier per K-step.  Tile s+1 (global loads issued a whole K-step
-// earlier) is written into the other LDS buffer before tile s's MFMAs; the loads of tile s+2 are
-// issued next and fly under those MFMAs.  (tap, ci) advance incrementally: no division per step.
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv3x3_mfma_db_kernel(const float* __restrict__ in, int H, int W,
-                                                              int Cin, const float* __restrict__ wt,
-                                                              const float* __restrict__ bias, int Cout,
-                                                              const float* __restrict__ mask,
-                                                              float* __restrict__ out, int relu) {
-  constexpr int A_FL = OperandLds<BM>::kc_floats, B_FL = OperandLds<BN>::kc_floats;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FL + B_FL)];
-  const int HW = H * W;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int t = threadIdx.x, c4 = t & 7, r0 = t >> 3;
-
-  int py[BM / 32], px[BM / 32];
+// ---- pipelined kernel (mfma_pipe.h): implicit-GEMM loaders for the 3x3 gather -----------------
+template <class Cfg>
+struct ConvALoader {   // A(pixel, k) = in[pixel + tap offset][ci]; out-of-image taps are zeros
+  const float* in;
+  int base[Cfg::NA];
+  unsigned tapmask[Cfg::NA];
+  int tap, ci0, off, Cin, W;
+  __device__ __forceinline__ ConvALoader(const float* in_, int H, int W_, int Cin_, int m0) : in(in_), tap(0), ci0(0), Cin(Cin_), W(W_) {
+    const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    const int HW = H * W_;
 #pragma unroll
-  for (int i = 0; i < BM / 32; ++i) {
-    const int p = m0 + r0 + 32 * i;
-    if (p < HW) { py[i] = p / W; px[i] = p - py[i] * W; }
-    else { py[i] = -4; px[i] = -4; }
-  }
-  const int steps = 9 * (Cin >> 5);
-  int tap = 0, ci0 = 0;      // state of the NEXT load
-  f32x4 ra[BM / 32], rb[BN / 32];
-  auto load = [&]() {
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    for (int i = 0; i < Cfg::NA; ++i) {
+      const int p = m0 + r0 + Cfg::RPP * i;
+      unsigned mk = 0;
+      int pc = 0;
+      if (p < HW) {
+        pc = p;
+        const int y = p / W_, x = p - y * W_;
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-      const int yy = py[i] + dy, xx = px[i] + dx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-        v = *reinterpret_cast<const f32x4*>(&in[((size_t)yy * W + xx) * Cin + ci0 + c4 * 4]);
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
-      const int co = n0 + r0 + 32 * i;
-      rb[i] = *reinterpret_cast<const f32x4*>(&wt[((size_t)tap * Cout + co) * Cin + ci0 + c4 * 4]);
-    }
-    ci0 += 32;
-    if (ci0 == Cin) { ci0 = 0; ++tap; }
-  };
-
-  f32x16 acc[BM / 64][BN / 64];
-  acc_zero<BM, BN>(acc);
-  load();
-  lds_store_kc<BM>(lds, ra);
-  lds_store_kc<BN>(lds + A_FL, rb);
-  if (steps > 1) load();
-  __syncthreads();
-  for (int s = 0; s < steps; ++s) {
-    float* cur = lds + (s & 1) * (A_FL + B_FL);
-    float* nxt = lds + ((s + 1) & 1) * (A_FL + B_FL);
-    if (s + 1 < steps) {
-      lds_store_kc<BM>(nxt, ra);
-      lds_store_kc<BN>(nxt + A_FL, rb);
-    }
-    if (s + 2 < steps) load();
-    mma_kstep<BM, BN, true, true>(cur, cur + A_FL, acc);
-    __syncthreads();
-  }
-
-  AccMap<BM, BN> map;
-#pragma unroll
-  for (int in_ = 0; in_ < BN / 64; ++in_) {
-    const int co = n0 + map.colof(in_);
-    const float b = bias ? bias[co] : 0.f;
-#pragma unroll
-    for (int im = 0; im < BM / 64; ++im)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int p = m0 + map.row(im, reg);
-        if (p < HW) {
-          float v = acc[im][in_][reg] + b;
-          if (relu) v = fmaxf(v, 0.f);
-          const size_t o = (size_t)p * Cout + co;
-          if (mask) v = (mask[o] > 0.f) ? v : 0.f;
-          out[o] = v;
+        for (int tp = 0; tp < 9; ++tp) {
+          const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W_) mk |= 1u << tp;
         }
       }
-  }
-}
-
-// v3: v2 + (a) branch-free staging loads (clamped address now, select-to-zero deferred to the LDS
-// store one K-step later, so no load is waited for at issue; no end-of-loop branches: the last two
-// iterations reload / rewrite harmlessly), (b) register double-buffered MFMA fragments, (c) the
-// staging work of a K-step (LDS writes of tile s+1, global loads of tile s+2) is cut into 4 pieces
-// pinned between the MFMA groups with sched_barrier, so it executes in the shadow of the 64-cycle
-// f32 MFMAs instead of in front of them; (d) the epilogue batches its mask loads.
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv3x3_mfma_v3_kernel(const float* __restrict__ in, int H, int W,
-                                                              int Cin, const float* __restrict__ wt,
-                                                              const float* __restrict__ bias, int Cout,
-                                                              const float* __restrict__ mask,
-                                                              float* __restrict__ out, int relu) {
-  constexpr int A_FL = OperandLds<BM>::kc_floats, B_FL = OperandLds<BN>::kc_floats;
-  constexpr int TM = BM / 64, TN = BN / 64, NA = BM / 32, NB = BN / 32;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FL + B_FL)];
-  const int HW = H * W;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int t = threadIdx.x, c4 = t & 7, r0 = t >> 3;
-  const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
-
-  // per staged row: element offset of its own pixel (clamped) and the taps that are in bounds
-  int abase[NA];
-  unsigned amask[NA];
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int p = m0 + r0 + 32 * i;
-    unsigned mk = 0;
-    int pc = 0;
-    if (p < HW) {
-      pc = p;
-      const int y = p / W, x = p - y * W;
-#pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << tp;
-      }
+      base[i] = pc * Cin_ + c4 * 4;
+      tapmask[i] = mk;
     }
-    abase[i] = pc * Cin + c4 * 4;
-    amask[i] = mk;
+    off = (-W_ - 1) * Cin_;
   }
-  int bbase[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) bbase[i] = (n0 + r0 + 32 * i) * Cin + c4 * 4;
-
-  const int steps = 9 * (Cin >> 5);
-  int tap = 0, ci0 = 0;            // (tap, ci) of the NEXT tile to load
-  int aoff = (-W - 1) * Cin;       // uniform element offset of that tile's tap: (dy*W + dx)*Cin + ci0
-  int boff = 0;                    // tap*Cout*Cin + ci0
-  f32x4 ra[NA], rb[NB];
-  unsigned okbits = 0;             // bit i: ra[i] (the tile held in registers) is an in-bounds tap
-
-  auto load_a = [&](int i) {
-    const bool ok = (amask[i] >> tap) & 1u;
-    ra[i] = *reinterpret_cast<const f32x4*>(in + (ok ? abase[i] + aoff : abase[i]));
-    okbits = (okbits & ~(1u << i)) | ((unsigned)ok << i);
-  };
-  auto load_b = [&](int i) { rb[i] = *reinterpret_cast<const f32x4*>(wt + bbase[i] + boff); };
-  auto advance = [&]() {
-    ci0 += 32; aoff += 32; boff += 32;
+  __device__ __forceinline__ void load(int i, f32x4& v, bool& ok) const {
+    ok = (tapmask[i] >> tap) & 1u;
+    v = *reinterpret_cast<const f32x4*>(in + (ok ? base[i] + off : base[i]));
+  }
+  __device__ __forceinline__ void advance() {
+    ci0 += 32; off += 32;
     if (ci0 == Cin) {
       ci0 = 0; ++tap;
-      if (tap == 9) tap = 0;     // past the end: wrap, so the (unused) extra loads stay in bounds
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      aoff = (dy * W + dx) * Cin;
-      boff = tap * Cout * Cin;
+      if (tap == 9) tap = 0;      // past the end: wrap, the (unused) extra loads stay in bounds
+      off = ((tap / 3 - 1) * W + (tap - (tap / 3) * 3 - 1)) * Cin;
     }
-  };
-  auto store_a = [&](float* buf, int i) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(&buf[(r0 + 32 * i) * KC_LD + c4 * 4]) = ((okbits >> i) & 1u) ? ra[i] : z;
-  };
-  auto store_b = [&](float* buf, int i) {
-    *reinterpret_cast<f32x4*>(&buf[A_FL + (r0 + 32 * i) * KC_LD + c4 * 4]) = rb[i];
-  };
-
-  f32x16 acc[TM][TN];
-  acc_zero<BM, BN>(acc);
-  // prologue: tile 0 -> buffer 0, tile 1 -> registers
-#pragma unroll
-  for (int i = 0; i < NA; ++i) load_a(i);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) load_b(i);
-  advance();
-#pragma unroll
-  for (int i = 0; i < NA; ++i) store_a(lds, i);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) store_b(lds, i);
-#pragma unroll
-  for (int i = 0; i < NA; ++i) load_a(i);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) load_b(i);
-  advance();
-  __syncthreads();
-
-  const int arow = (wm * (BM / 2) + l31) * KC_LD + 4 * hh;
-  const int brow = A_FL + (wn * (BN / 2) + l31) * KC_LD + 4 * hh;
-  // fragments of k-group 0 of the first tile; afterwards they are fetched right after the
-  // (early) barrier of the previous K-step, under its last MFMAs
-  f32x4 fa[2][TM], fb[2][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&lds[arow + i * 32 * KC_LD]);
-#pragma unroll
-  for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&lds[brow + i * 32 * KC_LD]);
-  for (int s = 0; s < steps; ++s) {
-    const float* cur = lds + (s & 1) * (A_FL + B_FL);
-    float* nxt = lds + ((s + 1) & 1) * (A_FL + B_FL);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g < 3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&cur[arow + i * 32 * KC_LD + 8 * (g + 1)]);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-          fb[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&cur[brow + i * 32 * KC_LD + 8 * (g + 1)]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int im = 0; im < TM; ++im)
-#pragma unroll
-          for (int in_ = 0; in_ < TN; ++in_)
-            acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][im][j], fb[g & 1][in_][j], acc[im][in_], 0, 0, 0);
-        if (j == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-          // staging piece g: rows {g, g+4, ...} of A -> LDS (tile s+1), then reload them (tile s+2)
-#pragma unroll
-          for (int i = g; i < NA; i += 4) { store_a(nxt, i); load_a(i); }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (j == 1) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = g; i < NB; i += 4) { store_b(nxt, i); load_b(i); }
-          __builtin_amdgcn_sched_barrier(0);
-          if (g == 3) {
-            // Every wave has issued all its reads of `cur` (k-group 3's fragments were read during
-            // group 2) and all its writes of `nxt`: one barrier here orders both, and the first
-            // fragments of the next tile are fetched under the 8 MFMAs that remain.
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&nxt[arow + i * 32 * KC_LD]);
-#pragma unroll
-            for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&nxt[brow + i * 32 * KC_LD]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-    advance();
   }
-
-  AccMap<BM, BN> map;
+};
+template <class Cfg>
+struct ConvBLoader {   // B(co, k) = wt[tap][co][ci]
+  const float* wt;
+  int base[Cfg::NB];
+  int tap, ci0, off, Cin, CoutCin;
+  __device__ __forceinline__ ConvBLoader(const float* wt_, int Cin_, int Cout, int n0) : wt(wt_), tap(0), ci0(0), off(0), Cin(Cin_), CoutCin(Cout * Cin_) {
+    const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 #pragma unroll
-  for (int in_ = 0; in_ < TN; ++in_) {
+    for (int i = 0; i < Cfg::NB; ++i) base[i] = (n0 + r0 + Cfg::RPP * i) * Cin_ + c4 * 4;
+  }
+  __device__ __forceinline__ void load(int i, f32x4& v, bool& ok) const {
+    ok = true;
+    v = *reinterpret_cast<const f32x4*>(wt + base[i] + off);
+  }
+  __device__ __forceinline__ void advance() {
+    ci0 += 32; off += 32;
+    if (ci0 == Cin) { ci0 = 0; ++tap; if (tap == 9) tap = 0; off = tap * CoutCin; }
+  }
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_pipe_kernel(const float* __restrict__ in, int H, int W,
+                                                                    int Cin, const float* __restrict__ wt,
+                                                                    const float* __restrict__ bias, int Cout,
+                                                                    const float* __restrict__ mask,
+                                                                    float* __restrict__ out, int relu) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int HW = H * W;
+  const int m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  ConvALoader<Cfg> la(in, H, W, Cin, m0);
+  ConvBLoader<Cfg> lb(wt, Cin, Cout, n0);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  pipe_mainloop<Cfg>(lds, 9 * (Cin >> 5), la, lb, acc);
+
+  PipeAccMap<Cfg> map;
+#pragma unroll
+  for (int in_ = 0; in_ < Cfg::TN; ++in_) {
     const int co = n0 + map.colof(in_);
     const float b = bias ? bias[co] : 0.f;
 #pragma unroll
-    for (int im = 0; im < TM; ++im) {
+    for (int im = 0; im < Cfg::TM; ++im) {
       float mv[16];
       if (mask) {      // uniform branch; the 16 loads inside are issued back to back, clamped in bounds
 #pragma unroll
@@ -364,7 +208,16 @@ static int conv_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("STROTSS_CONV_VARIANT");
-    v = e ? atoi(e) : 3;
+    v = e ? atoi(e) : 3;   // 1 = simple two-barrier kernel (kept for A/B), otherwise the pipelined one
+  }
+  return v;
+}
+
+static int conv_waves() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STROTSS_CONV_WAVES");
+    v = e ? atoi(e) : 4;
   }
   return v;
 }
@@ -373,15 +226,24 @@ template <int BM, int BN>
 int launch_conv(const float* in, int H, int W, int Cin, const float* wt, const float* bias, int Cout,
                 const float* mask, float* out, int relu, hipStream_t s) {
   dim3 grid(Cout / BN, cdiv((int64_t)H * W, BM));
-  if (conv_variant() == 1)
+  if (conv_variant() == 1) {
     hipLaunchKernelGGL((conv3x3_mfma_kernel<BM, BN>), grid, dim3(256), 0, s, in, H, W, Cin, wt, bias, Cout,
                        mask, out, relu);
-  else if (conv_variant() == 2)
-    hipLaunchKernelGGL((conv3x3_mfma_db_kernel<BM, BN>), grid, dim3(256), 0, s, in, H, W, Cin, wt, bias, Cout,
+    ST_LAUNCH_RET();
+  }
+  if constexpr (BM == 128) {
+    if (conv_waves() == 8) {
+      using Cfg = PipeCfg<BM, BN, (BN == 128 ? 2 : 4), (BN == 128 ? 4 : 2)>;
+      hipLaunchKernelGGL((conv3x3_mfma_pipe_kernel<Cfg>), grid, dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, bias, Cout,
+                         mask, out, relu);
+      ST_LAUNCH_RET();
+    }
+  }
+  {
+    using Cfg = PipeCfg<BM, BN, 2, 2>;
+    hipLaunchKernelGGL((conv3x3_mfma_pipe_kernel<Cfg>), grid, dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, bias, Cout,
                        mask, out, relu);
-  else
-    hipLaunchKernelGGL((conv3x3_mfma_v3_kernel<BM, BN>), grid, dim3(256), 0, s, in, H, W, Cin, wt, bias, Cout,
-                       mask, out, relu);
+  }
   ST_LAUNCH_RET();
 }
 

@@ -1,7 +1,9 @@
 // fp32-MFMA GEMMs of the loss path (cost matrices, covariance, their backward products).
 // All are C[m][n] = sum_k A(m,k) B(n,k) on the tile engine of mfma_tile.h with fused epilogues.
+#include <stdlib.h>
+
 #include "internal.h"
-#include "mfma_tile.h"
+#include "mfma_pipe.h"
 
 namespace {
 
@@ -111,129 +113,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
   epi.finish(lds, local);
 }
 
-// Pipelined K-contiguous x K-contiguous GEMM (same structure as conv3x3_mfma_v3_kernel in conv.hip):
-// double-buffered LDS, ONE barrier per K-step placed before the last 8 MFMAs, register
-// double-buffered fragments, staging (LDS writes of tile s+1 / global loads of tile s+2) pinned
-// between the MFMA groups.  Batched over blockIdx.z (strideA/strideB elements, epi.set_batch(z)).
-template <int BM, int BN, class Epi>
-__global__ __launch_bounds__(256) void gemm_kc_pipe_kernel(const float* __restrict__ A, int lda, int M,
-                                                           long long strideA, const float* __restrict__ B,
-                                                           int ldb, int N, long long strideB, int K, Epi epi) {
-  constexpr int A_FL = OperandLds<BM>::kc_floats, B_FL = OperandLds<BN>::kc_floats;
-  constexpr int TM = BM / 64, TN = BN / 64, NA = BM / 32, NB = BN / 32;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FL + B_FL)];
+// Pipelined K-contiguous x K-contiguous GEMM on the shared main loop of mfma_pipe.h.
+// Batched over blockIdx.z (strideA/strideB elements, epi.set_batch(z)).
+template <class Cfg, class Epi>
+__global__ __launch_bounds__(Cfg::NT) void gemm_kc_pipe_kernel(const float* __restrict__ A, int lda, int M,
+                                                               long long strideA, const float* __restrict__ B,
+                                                               int ldb, int N, long long strideB, int K, Epi epi) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   A += (long long)blockIdx.z * strideA;
   B += (long long)blockIdx.z * strideB;
   epi.set_batch(blockIdx.z);
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int t = threadIdx.x, c4 = t & 7, r0 = t >> 3;
-  const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
-
-  size_t abase[NA], bbase[NB];
-  unsigned aok = 0, bok = 0;      // rows inside the matrix (others are staged as zeros)
+  const int m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  RowMajorLoader<Cfg, Cfg::NA> la(A, lda, m0, M, K);
+  RowMajorLoader<Cfg, Cfg::NB> lb(B, ldb, n0, N, K);
+  f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int r = m0 + r0 + 32 * i;
-    aok |= (unsigned)(r < M) << i;
-    abase[i] = (size_t)min(r, M - 1) * lda + c4 * 4;
-  }
+  for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int r = n0 + r0 + 32 * i;
-    bok |= (unsigned)(r < N) << i;
-    bbase[i] = (size_t)min(r, N - 1) * ldb + c4 * 4;
-  }
-  const int steps = K >> 5;
-  int k0 = 0;                      // K offset of the NEXT tile to load (wraps past the end)
-  f32x4 ra[NA], rb[NB];
-  auto load_a = [&](int i) { ra[i] = *reinterpret_cast<const f32x4*>(A + abase[i] + k0); };
-  auto load_b = [&](int i) { rb[i] = *reinterpret_cast<const f32x4*>(B + bbase[i] + k0); };
-  auto advance = [&]() { k0 += 32; if (k0 >= K) k0 = 0; };
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  auto store_a = [&](float* buf, int i) {
-    *reinterpret_cast<f32x4*>(&buf[(r0 + 32 * i) * KC_LD + c4 * 4]) = ((aok >> i) & 1u) ? ra[i] : z4;
-  };
-  auto store_b = [&](float* buf, int i) {
-    *reinterpret_cast<f32x4*>(&buf[A_FL + (r0 + 32 * i) * KC_LD + c4 * 4]) = ((bok >> i) & 1u) ? rb[i] : z4;
-  };
-
-  f32x16 acc[TM][TN];
-  acc_zero<BM, BN>(acc);
+    for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
-  for (int i = 0; i < NA; ++i) load_a(i);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) load_b(i);
-  advance();
-#pragma unroll
-  for (int i = 0; i < NA; ++i) store_a(lds, i);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) store_b(lds, i);
-#pragma unroll
-  for (int i = 0; i < NA; ++i) load_a(i);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) load_b(i);
-  advance();
-  __syncthreads();
-
-  const int arow = (wm * (BM / 2) + l31) * KC_LD + 4 * hh;
-  const int brow = A_FL + (wn * (BN / 2) + l31) * KC_LD + 4 * hh;
-  f32x4 fa[2][TM], fb[2][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&lds[arow + i * 32 * KC_LD]);
-#pragma unroll
-  for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&lds[brow + i * 32 * KC_LD]);
-  for (int s = 0; s < steps; ++s) {
-    const float* cur = lds + (s & 1) * (A_FL + B_FL);
-    float* nxt = lds + ((s + 1) & 1) * (A_FL + B_FL);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g < 3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&cur[arow + i * 32 * KC_LD + 8 * (g + 1)]);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-          fb[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&cur[brow + i * 32 * KC_LD + 8 * (g + 1)]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int im = 0; im < TM; ++im)
-#pragma unroll
-          for (int in_ = 0; in_ < TN; ++in_)
-            acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][im][j], fb[g & 1][in_][j], acc[im][in_], 0, 0, 0);
-        if (j == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = g; i < NA; i += 4) { store_a(nxt, i); load_a(i); }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (j == 1) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = g; i < NB; i += 4) { store_b(nxt, i); load_b(i); }
-          __builtin_amdgcn_sched_barrier(0);
-          if (g == 3) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&nxt[arow + i * 32 * KC_LD]);
-#pragma unroll
-            for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&nxt[brow + i * 32 * KC_LD]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-    advance();
-  }
-  AccMap<BM, BN> map;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  pipe_mainloop<Cfg>(lds, K >> 5, la, lb, acc);
+  PipeAccMap<Cfg> map;
   float local = 0.f;
 #pragma unroll
-  for (int im = 0; im < TM; ++im)
+  for (int im = 0; im < Cfg::TM; ++im)
 #pragma unroll
-    for (int in = 0; in < TN; ++in)
+    for (int in = 0; in < Cfg::TN; ++in)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
         local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
@@ -241,12 +147,32 @@ __global__ __launch_bounds__(256) void gemm_kc_pipe_kernel(const float* __restri
   epi.finish(lds, local);
 }
 
+static int gemm_waves() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STROTSS_GEMM_WAVES");
+    v = e ? atoi(e) : 4;
+  }
+  return v;
+}
+
 template <int BM, int BN, class Epi>
 int launch_pipe(const float* A, int lda, int M, long long strideA, const float* B, int ldb, int N,
                 long long strideB, int K, int batch, Epi epi, hipStream_t s) {
   dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
-  hipLaunchKernelGGL((gemm_kc_pipe_kernel<BM, BN, Epi>), grid, dim3(256), 0, s, A, lda, M, strideA, B, ldb, N,
-                     strideB, K, epi);
+  if constexpr (BM == 128) {
+    if (gemm_waves() == 8) {
+      using Cfg = PipeCfg<BM, BN, (BN == 128 ? 2 : 4), (BN == 128 ? 4 : 2)>;
+      hipLaunchKernelGGL((gemm_kc_pipe_kernel<Cfg, Epi>), grid, dim3(Cfg::NT), 0, s, A, lda, M, strideA, B, ldb, N,
+                         strideB, K, epi);
+      ST_LAUNCH_RET();
+    }
+  }
+  {
+    using Cfg = PipeCfg<BM, BN, 2, 2>;
+    hipLaunchKernelGGL((gemm_kc_pipe_kernel<Cfg, Epi>), grid, dim3(Cfg::NT), 0, s, A, lda, M, strideA, B, ldb, N,
+                       strideB, K, epi);
+  }
   ST_LAUNCH_RET();
 }
 

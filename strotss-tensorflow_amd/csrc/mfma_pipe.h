@@ -1,0 +1,155 @@
+// Pipelined f32-MFMA main loop shared by the direct 3x3 conv (conv.hip) and the K-contiguous GEMMs
+// (gemm.hip: Winograd-domain GEMMs, cosine cost matrices, moment backward).
+//
+// Block tile BM x BN, K-step 32, WM x WN waves (each (BM/WM) x (BN/WN) as 32x32 MFMA tiles).
+//   * double-buffered LDS ([row][36] images, conflict-free ds_read_b128 / ds_write_b128);
+//   * per K-step ONE barrier, placed before the last 8 MFMAs of the step: by then every wave has
+//     issued all its reads of the current buffer and all its writes of the next one, so the first
+//     fragments of the next tile are fetched under the remaining MFMAs;
+//   * MFMA fragments are register double-buffered (k-group t+1 is read before group t's MFMAs);
+//   * the staging work of a step (LDS writes of tile s+1, global loads of tile s+2) is cut into 4
+//     pieces pinned between the MFMA groups with sched_barrier: it runs in the shadow of the
+//     64-cycle f32 MFMAs.  Loads are branch-free (clamped address); rows/taps outside the operand
+//     are zeroed at the LDS store one step later, so no load is waited for at issue.
+//
+// Loader protocol (functor L):  L.load(i, v, ok): raw 16-byte load of staged row i of the NEXT
+// tile (ok = false -> store zeros instead), L.advance(): move to the following tile; loads past the
+// last tile must stay in bounds (wrap) -- their data is never used.
+#pragma once
+#include "mfma_tile.h"
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct PipeCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int NT = 64 * WM_ * WN_;          // threads
+  static constexpr int RPP = NT / 8;                 // rows staged per pass (8 lanes x 16 B per row)
+  static constexpr int NA = BM_ / RPP, NB = BN_ / RPP;
+  static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
+  static constexpr int A_FL = BM_ * KC_LD, B_FL = BN_ * KC_LD;
+  static constexpr int LDS_FLOATS = 2 * (A_FL + B_FL);
+  static_assert(NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1, "tile too small for this wave grid");
+};
+
+template <class Cfg>
+struct PipeAccMap {   // accumulator element -> (row, col) in the block tile (32x32 MFMA C/D layout)
+  int row_base, col;
+  __device__ __forceinline__ PipeAccMap() {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    row_base = (wave / Cfg::WN) * (Cfg::BM / Cfg::WM) + 4 * (lane >> 5);
+    col = (wave % Cfg::WN) * (Cfg::BN / Cfg::WN) + (lane & 31);
+  }
+  __device__ __forceinline__ int row(int im, int reg) const { return row_base + im * 32 + (reg & 3) + 8 * (reg >> 2); }
+  __device__ __forceinline__ int colof(int in) const { return col + in * 32; }
+};
+
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void pipe_mainloop(float* lds, int steps, LA& la, LB& lb,
+                                              f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB, A_FL = Cfg::A_FL, B_FL = Cfg::B_FL;
+  const int t = threadIdx.x, c4 = t & 7, r0 = t >> 3;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN, l31 = lane & 31, hh = lane >> 5;
+  f32x4 ra[NA], rb[NB];
+  unsigned oka = 0, okb = 0;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_a = [&](int i) { bool ok; la.load(i, ra[i], ok); oka = (oka & ~(1u << i)) | ((unsigned)ok << i); };
+  auto load_b = [&](int i) { bool ok; lb.load(i, rb[i], ok); okb = (okb & ~(1u << i)) | ((unsigned)ok << i); };
+  auto store_a = [&](float* buf, int i) {
+    *reinterpret_cast<f32x4*>(&buf[(r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = ((oka >> i) & 1u) ? ra[i] : z4;
+  };
+  auto store_b = [&](float* buf, int i) {
+    *reinterpret_cast<f32x4*>(&buf[A_FL + (r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = ((okb >> i) & 1u) ? rb[i] : z4;
+  };
+  // prologue: tile 0 -> buffer 0, tile 1 -> registers
+#pragma unroll
+  for (int i = 0; i < NA; ++i) load_a(i);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) load_b(i);
+  la.advance(); lb.advance();
+#pragma unroll
+  for (int i = 0; i < NA; ++i) store_a(lds, i);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) store_b(lds, i);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) load_a(i);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) load_b(i);
+  la.advance(); lb.advance();
+  __syncthreads();
+
+  const int arow = (wm * (Cfg::BM / Cfg::WM) + l31) * KC_LD + 4 * hh;
+  const int brow = A_FL + (wn * (Cfg::BN / Cfg::WN) + l31) * KC_LD + 4 * hh;
+  f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&lds[arow + i * 32 * KC_LD]);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&lds[brow + i * 32 * KC_LD]);
+  for (int s = 0; s < steps; ++s) {
+    const float* cur = lds + (s & 1) * (A_FL + B_FL);
+    float* nxt = lds + ((s + 1) & 1) * (A_FL + B_FL);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&cur[arow + i * 32 * KC_LD + 8 * (g + 1)]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          fb[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&cur[brow + i * 32 * KC_LD + 8 * (g + 1)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in_ = 0; in_ < TN; ++in_)
+            acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][im][j], fb[g & 1][in_][j], acc[im][in_], 0, 0, 0);
+        if (j == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = g; i < NA; i += 4) { store_a(nxt, i); load_a(i); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = g; i < NB; i += 4) { store_b(nxt, i); load_b(i); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (g == 3) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&nxt[arow + i * 32 * KC_LD]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&nxt[brow + i * 32 * KC_LD]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+    la.advance(); lb.advance();
+  }
+}
+
+// Plain row-major K-contiguous operand: element (row, k) at p[row*ld + k]; rows >= nrows are zeros.
+template <class Cfg, int NROWS_STAGED>
+struct RowMajorLoader {
+  const float* p;
+  size_t base[NROWS_STAGED];
+  unsigned ok;
+  int k0, K;
+  __device__ __forceinline__ RowMajorLoader(const float* ptr, int ld, int row0, int nrows, int K_) : p(ptr), ok(0), k0(0), K(K_) {
+    const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < NROWS_STAGED; ++i) {
+      const int r = row0 + r0 + Cfg::RPP * i;
+      ok |= (unsigned)(r < nrows) << i;
+      base[i] = (size_t)min(r, nrows - 1) * ld + c4 * 4;
+    }
+  }
+  __device__ __forceinline__ void load(int i, f32x4& v, bool& o) const {
+    v = *reinterpret_cast<const f32x4*>(p + base[i] + k0);
+    o = (ok >> i) & 1u;
+  }
+  __device__ __forceinline__ void advance() { k0 += 32; if (k0 >= K) k0 = 0; }
+};

@@ -96,8 +96,10 @@ struct ConvALoader {   // A(pixel, k) = in[pixel + tap offset][ci]; out-of-image
   const float* in;
   int base[Cfg::NA];
   unsigned tapmask[Cfg::NA];
+  f32x4 r[Cfg::NA];
+  unsigned okbits;
   int tap, ci0, off, Cin, W;
-  __device__ __forceinline__ ConvALoader(const float* in_, int H, int W_, int Cin_, int m0) : in(in_), tap(0), ci0(0), Cin(Cin_), W(W_) {
+  __device__ __forceinline__ ConvALoader(const float* in_, int H, int W_, int Cin_, int m0) : in(in_), okbits(0), tap(0), ci0(0), Cin(Cin_), W(W_) {
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
     const int HW = H * W_;
 #pragma unroll
@@ -119,9 +121,14 @@ struct ConvALoader {   // A(pixel, k) = in[pixel + tap offset][ci]; out-of-image
     }
     off = (-W_ - 1) * Cin_;
   }
-  __device__ __forceinline__ void load(int i, f32x4& v, bool& ok) const {
-    ok = (tapmask[i] >> tap) & 1u;
-    v = *reinterpret_cast<const f32x4*>(in + (ok ? base[i] + off : base[i]));
+  __device__ __forceinline__ void issue(int i) {
+    const bool ok = (tapmask[i] >> tap) & 1u;
+    r[i] = *reinterpret_cast<const f32x4*>(in + (ok ? base[i] + off : base[i]));
+    okbits = (okbits & ~(1u << i)) | ((unsigned)ok << i);
+  }
+  __device__ __forceinline__ f32x4 value(int i) const {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    return ((okbits >> i) & 1u) ? r[i] : z4;
   }
   __device__ __forceinline__ void advance() {
     ci0 += 32; off += 32;
@@ -136,16 +143,15 @@ template <class Cfg>
 struct ConvBLoader {   // B(co, k) = wt[tap][co][ci]
   const float* wt;
   int base[Cfg::NB];
+  f32x4 r[Cfg::NB];
   int tap, ci0, off, Cin, CoutCin;
   __device__ __forceinline__ ConvBLoader(const float* wt_, int Cin_, int Cout, int n0) : wt(wt_), tap(0), ci0(0), off(0), Cin(Cin_), CoutCin(Cout * Cin_) {
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 #pragma unroll
     for (int i = 0; i < Cfg::NB; ++i) base[i] = (n0 + r0 + Cfg::RPP * i) * Cin_ + c4 * 4;
   }
-  __device__ __forceinline__ void load(int i, f32x4& v, bool& ok) const {
-    ok = true;
-    v = *reinterpret_cast<const f32x4*>(wt + base[i] + off);
-  }
+  __device__ __forceinline__ void issue(int i) { r[i] = *reinterpret_cast<const f32x4*>(wt + base[i] + off); }
+  __device__ __forceinline__ f32x4 value(int i) const { return r[i]; }
   __device__ __forceinline__ void advance() {
     ci0 += 32; off += 32;
     if (ci0 == Cin) { ci0 = 0; ++tap; if (tap == 9) tap = 0; off = tap * CoutCin; }

@@ -16,6 +16,9 @@ int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, cons
 int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                        float* C, int ldc, long long strideC, int M, int N, int K, int batch, hipStream_t s);
 
+int st_winograd_gemm_fused(const float* in, int H, int W, int C, int TW, int T, const float* U, int N, float* Mw,
+                           hipStream_t s);
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Bump allocator over a caller-provided workspace (256-byte aligned slices).

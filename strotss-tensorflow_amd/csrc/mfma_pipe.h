@@ -12,9 +12,12 @@
 //     64-cycle f32 MFMAs.  Loads are branch-free (clamped address); rows/taps outside the operand
 //     are zeroed at the LDS store one step later, so no load is waited for at issue.
 //
-// Loader protocol (functor L):  L.load(i, v, ok): raw 16-byte load of staged row i of the NEXT
-// tile (ok = false -> store zeros instead), L.advance(): move to the following tile; loads past the
-// last tile must stay in bounds (wrap) -- their data is never used.
+// Loader protocol (functor L, owns its staging registers):
+//   L.issue(i)  : issue the raw 16-byte load(s) of staged row i of the NEXT tile (no use of the data);
+//   L.value(i)  : the f32x4 to put in LDS for row i of the tile issued ONE step earlier (this is where
+//                 out-of-range rows/taps become zeros and where fused transforms combine their loads);
+//   L.advance() : move to the following tile; loads past the last tile must stay in bounds (wrap) --
+//                 their data is never used.
 #pragma once
 #include "mfma_tile.h"
 
@@ -49,16 +52,13 @@ __device__ __forceinline__ void pipe_mainloop(float* lds, int steps, LA& la, LB&
   const int t = threadIdx.x, c4 = t & 7, r0 = t >> 3;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN, l31 = lane & 31, hh = lane >> 5;
-  f32x4 ra[NA], rb[NB];
-  unsigned oka = 0, okb = 0;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  auto load_a = [&](int i) { bool ok; la.load(i, ra[i], ok); oka = (oka & ~(1u << i)) | ((unsigned)ok << i); };
-  auto load_b = [&](int i) { bool ok; lb.load(i, rb[i], ok); okb = (okb & ~(1u << i)) | ((unsigned)ok << i); };
+  auto load_a = [&](int i) { la.issue(i); };
+  auto load_b = [&](int i) { lb.issue(i); };
   auto store_a = [&](float* buf, int i) {
-    *reinterpret_cast<f32x4*>(&buf[(r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = ((oka >> i) & 1u) ? ra[i] : z4;
+    *reinterpret_cast<f32x4*>(&buf[(r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = la.value(i);
   };
   auto store_b = [&](float* buf, int i) {
-    *reinterpret_cast<f32x4*>(&buf[A_FL + (r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = ((okb >> i) & 1u) ? rb[i] : z4;
+    *reinterpret_cast<f32x4*>(&buf[A_FL + (r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = lb.value(i);
   };
   // prologue: tile 0 -> buffer 0, tile 1 -> registers
 #pragma unroll
@@ -136,20 +136,22 @@ template <class Cfg, int NROWS_STAGED>
 struct RowMajorLoader {
   const float* p;
   size_t base[NROWS_STAGED];
+  f32x4 r[NROWS_STAGED];
   unsigned ok;
   int k0, K;
   __device__ __forceinline__ RowMajorLoader(const float* ptr, int ld, int row0, int nrows, int K_) : p(ptr), ok(0), k0(0), K(K_) {
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 #pragma unroll
     for (int i = 0; i < NROWS_STAGED; ++i) {
-      const int r = row0 + r0 + Cfg::RPP * i;
-      ok |= (unsigned)(r < nrows) << i;
-      base[i] = (size_t)min(r, nrows - 1) * ld + c4 * 4;
+      const int row = row0 + r0 + Cfg::RPP * i;
+      ok |= (unsigned)(row < nrows) << i;
+      base[i] = (size_t)min(row, nrows - 1) * ld + c4 * 4;
     }
   }
-  __device__ __forceinline__ void load(int i, f32x4& v, bool& o) const {
-    v = *reinterpret_cast<const f32x4*>(p + base[i] + k0);
-    o = (ok >> i) & 1u;
+  __device__ __forceinline__ void issue(int i) { r[i] = *reinterpret_cast<const f32x4*>(p + base[i] + k0); }
+  __device__ __forceinline__ f32x4 value(int i) const {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    return ((ok >> i) & 1u) ? r[i] : z4;
   }
   __device__ __forceinline__ void advance() { k0 += 32; if (k0 >= K) k0 = 0; }
 };

@@ -9,6 +9,8 @@
 // U[p] = (G g G^T)[p] is pre-computed once per model on the host (frozen weights).  The two
 // transforms are streaming kernels (V and M are 4x the activation size; at the sizes used they
 // live in the 256 MiB Infinity Cache between producer and consumer).
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace {
@@ -119,10 +121,20 @@ int winograd_run(const float* in, int h, int w, int cin, const float* U, const f
   float* Mw = ws.take<float>(16 * T * cout);
   if (!ws.ok()) return STROTSS_EINVAL;
   const size_t tin = T * (cin / 4), tout = T * (cout / 4);
-  hipLaunchKernelGGL(winograd_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
-                     h, w, cin / 4, TH, TW, V);
-  int rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
-                              (long long)T * cout, (int)T, cout, cin, 16, st);
+  static int fused = -1;
+  if (fused < 0) { const char* e = getenv("STROTSS_WINO_FUSED"); fused = e ? atoi(e) : 0; }
+  int rc;
+  if (fused) {
+    // input transform folded into the GEMM's A loader (V never materialised).  Measured on MI355X:
+    // NOT faster (4x the staging loads, 243 VGPRs -> one wave per SIMD; V is absorbed by the
+    // Infinity Cache anyway), so it is off by default and kept for A/B (STROTSS_WINO_FUSED=1).
+    rc = st_winograd_gemm_fused(in, h, w, cin, TW, (int)T, U, cout, Mw, st);
+  } else {
+    hipLaunchKernelGGL(winograd_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
+                       in, h, w, cin / 4, TH, TW, V);
+    rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
+                            (long long)T * cout, (int)T, cout, cin, 16, st);
+  }
   if (rc != 0) return rc;
   hipLaunchKernelGGL(winograd_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
                      Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out);

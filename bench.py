@@ -256,9 +256,9 @@ def main():
         executed = 2.0 * sum(2.0 * (4 if "u_fwd" in L else 9) * L["cin"] * L["cout"] * a.shape[1] * a.shape[2]
                              for L, a in zip(params.layers, eng.trunk.acts) if L["cin"] != 3)
         tf = algo / (conv_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA: conv3x3_mfma_v3_kernel (direct implicit GEMM, Cin=64 "
+        out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA: conv3x3_mfma_pipe_kernel (direct implicit GEMM, Cin=64 "
                                      "layers) + gemm_kc_pipe_kernel (16 Winograd F(2x2,3x3) GEMMs, Cin>=128 layers) "
-                                     "incl. their transform kernels; fwd + dgrad, all launches of a step",
+                                     "incl. winograd_in/out_kernel; fwd + dgrad, all launches of a step",
                            "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                            "algorithmic_gflop_per_step": round(algo / 1e9, 1),

@@ -281,3 +281,33 @@ def test_cli_end_to_end(tmp_path):
     with pytest.raises(ValueError):
         bad = argparse.Namespace(**vars(args)); bad.content_mask = "x.jpg"; bad.style_mask = None
         RS.run(bad)
+
+
+def test_cli_with_masks(tmp_path):
+    """Region-guided run (run_strotss.py:52-59, 97-125): load_mask pairs the colour regions, every
+    region draws its own samples, one trunk pass serves all regions."""
+    from PIL import Image
+    import run_strotss as RS
+    from nn import strotss_utils as SU
+    rng = np.random.default_rng(1)
+    h, w = 128, 160
+    for name in ("c.jpg", "s.jpg"):
+        arr = (rng.random((h // 8, w // 8, 3)) * 255).astype(np.uint8)
+        Image.fromarray(arr).resize((w, h), Image.BILINEAR).save(tmp_path / name, quality=95)
+    cm = np.zeros((h, w, 3), np.uint8); cm[:, : w // 2] = 255      # white | black survive the JPEG round trip
+    sm = np.zeros((h, w, 3), np.uint8); sm[: h // 2] = 255
+    Image.fromarray(cm).save(tmp_path / "cm.jpg", quality=100, subsampling=0)
+    Image.fromarray(sm).save(tmp_path / "sm.jpg", quality=100, subsampling=0)
+    c_masks, s_masks = SU.load_mask(str(tmp_path / "cm.jpg"), str(tmp_path / "sm.jpg"), None, sample_threth=5000)
+    assert len(c_masks) == 2 and len(s_masks) == 2
+    tot = sum(float(m.sum()) for m in c_masks)
+    assert abs(tot - h * w) < 0.02 * h * w                       # the two regions tile the image (JPEG edge pixels aside)
+    with pytest.raises(Exception):
+        SU.load_mask(str(tmp_path / "cm.jpg"), str(tmp_path / "sm.jpg"), None, sample_threth=10 ** 9)
+    # the CLI default threshold (10000 px) also keeps both 10240-px regions
+    out = tmp_path / "out.jpg"
+    args = RS.build_parser().parse_args([str(tmp_path / "c.jpg"), str(tmp_path / "s.jpg"), "-o", str(out),
+                                         "--content_mask", str(tmp_path / "cm.jpg"), "--style_mask",
+                                         str(tmp_path / "sm.jpg"), "--level", "2", "--max_iter", "3"])
+    final = RS.run(args)
+    assert tuple(final.shape) == (102, 128, 3) and os.path.exists(out)

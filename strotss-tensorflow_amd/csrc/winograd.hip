@@ -12,16 +12,32 @@
 #include <stdlib.h>
 
 #include "internal.h"
+#include "mfma_split.h"
 
 namespace {
 
 // V: (16, T, C) with T = ceil(H/2)*ceil(W/2); tile (ty,tx) reads input rows 2ty-1..2ty+2, cols 2tx-1..2tx+2
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void winograd_in_kernel(const float* __restrict__ in, int H, int W, int C4,
                                                           int TH, int TW, float* __restrict__ V) {
   const size_t T = (size_t)TH * TW;
   const size_t total = T * C4;
   const f32x4* src = reinterpret_cast<const f32x4*>(in);
   f32x4* dst = reinterpret_cast<f32x4*>(V);
+  // SPLIT: V is three bf16 planes of (16, T, C) (plane stride 16*T*C elements), see mfma_split.h
+  __bf16* pl = reinterpret_cast<__bf16*>(V);
+  const size_t plane = (size_t)16 * T * C4 * 4;
+  auto put = [&](int pos, size_t tile, int c, const f32x4 v) {
+    const size_t o = ((size_t)pos * T + tile) * C4 + c;
+    if constexpr (SPLIT) {
+      const Split3 s3 = split3(v);
+      *reinterpret_cast<bf16x4*>(pl + 4 * o) = s3.h;
+      *reinterpret_cast<bf16x4*>(pl + plane + 4 * o) = s3.m;
+      *reinterpret_cast<bf16x4*>(pl + 2 * plane + 4 * o) = s3.l;
+    } else {
+      dst[o] = v;
+    }
+  };
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int c = (int)(e % C4);
     const size_t tile = e / C4;
@@ -52,10 +68,10 @@ __global__ __launch_bounds__(256) void winograd_in_kernel(const float* __restric
     for (int r = 0; r < 4; ++r) {
       const f32x4 v0 = tt[r][0] - tt[r][2], v1 = tt[r][1] + tt[r][2], v2 = tt[r][2] - tt[r][1],
                   v3 = tt[r][1] - tt[r][3];
-      dst[((size_t)(r * 4 + 0) * T + tile) * C4 + c] = v0;
-      dst[((size_t)(r * 4 + 1) * T + tile) * C4 + c] = v1;
-      dst[((size_t)(r * 4 + 2) * T + tile) * C4 + c] = v2;
-      dst[((size_t)(r * 4 + 3) * T + tile) * C4 + c] = v3;
+      put(r * 4 + 0, tile, c, v0);
+      put(r * 4 + 1, tile, c, v1);
+      put(r * 4 + 2, tile, c, v2);
+      put(r * 4 + 3, tile, c, v3);
     }
   }
 }
@@ -117,9 +133,17 @@ int winograd_run(const float* in, int h, int w, int cin, const float* U, const f
   const int TH = (h + 1) / 2, TW = (w + 1) / 2;
   const size_t T = (size_t)TH * TW;
   Workspace ws(workspace, workspace_bytes);
-  float* V = ws.take<float>(16 * T * cin);
+  float* V = ws.take<float>(16 * T * cin * 3 / 2 + 64);      // f32 V, or three bf16 planes (1.5x)
   float* Mw = ws.take<float>(16 * T * cout);
+  unsigned short* Up = ws.take<unsigned short>((size_t)3 * 16 * cout * cin);
   if (!ws.ok()) return STROTSS_EINVAL;
+  // EXPERIMENTAL, off by default: STROTSS_MFMA_SPLIT = 6 | 9 runs the 16 GEMMs on the bf16 MFMA by exact
+  // 3-way splitting (mfma_split.h); STROTSS_MFMA_SPLIT_APRE = 1 also pre-splits V in the input transform.
+  static int split = -1, apre = 0;
+  if (split < 0) {
+    const char* e = getenv("STROTSS_MFMA_SPLIT"); split = e ? atoi(e) : 0;
+    const char* a = getenv("STROTSS_MFMA_SPLIT_APRE"); apre = a ? atoi(a) : 0;
+  }
   const size_t tin = T * (cin / 4), tout = T * (cout / 4);
   static int fused = -1;
   if (fused < 0) { const char* e = getenv("STROTSS_WINO_FUSED"); fused = e ? atoi(e) : 0; }
@@ -130,10 +154,24 @@ int winograd_run(const float* in, int h, int w, int cin, const float* U, const f
     // Infinity Cache anyway), so it is off by default and kept for A/B (STROTSS_WINO_FUSED=1).
     rc = st_winograd_gemm_fused(in, h, w, cin, TW, (int)T, U, cout, Mw, st);
   } else {
-    hipLaunchKernelGGL(winograd_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
-                       in, h, w, cin / 4, TH, TW, V);
-    rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
-                            (long long)T * cout, (int)T, cout, cin, 16, st);
+    if (split && cout % 128 == 0) {
+      const size_t nU = (size_t)16 * cout * cin, nV = (size_t)16 * T * cin;
+      if (apre)
+        hipLaunchKernelGGL(winograd_in_kernel<true>, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256),
+                           0, st, in, h, w, cin / 4, TH, TW, V);
+      else
+        hipLaunchKernelGGL(winograd_in_kernel<false>, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256),
+                           0, st, in, h, w, cin / 4, TH, TW, V);
+      rc = st_split_planes(U, nU, Up, st);
+      if (rc != 0) return rc;
+      rc = st_gemm_nt_batched_split(V, apre, nV, cin, (long long)T * cin, Up, nU, cin, (long long)cout * cin, Mw,
+                                    cout, (long long)T * cout, (int)T, cout, cin, 16, split, st);
+    } else {
+      hipLaunchKernelGGL(winograd_in_kernel<false>, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0,
+                         st, in, h, w, cin / 4, TH, TW, V);
+      rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
+                              (long long)T * cout, (int)T, cout, cin, 16, st);
+    }
   }
   if (rc != 0) return rc;
   hipLaunchKernelGGL(winograd_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
@@ -147,7 +185,8 @@ extern "C" {
 
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout) {
   const size_t T = (size_t)((h + 1) / 2) * ((w + 1) / 2);
-  return ws_slice(16 * T * cin, sizeof(float)) + ws_slice(16 * T * cout, sizeof(float));
+  return ws_slice(16 * T * cin * 3 / 2 + 64, sizeof(float)) + ws_slice(16 * T * cout, sizeof(float)) +
+         ws_slice((size_t)3 * 16 * cout * cin, sizeof(unsigned short));
 }
 
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok, const float* bias,

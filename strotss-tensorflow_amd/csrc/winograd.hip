@@ -19,8 +19,9 @@ namespace {
 // V: (16, T, C) with T = ceil(H/2)*ceil(W/2); tile (ty,tx) reads input rows 2ty-1..2ty+2, cols 2tx-1..2tx+2
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void winograd_in_kernel(const float* __restrict__ in, int H, int W, int C4,
-                                                          int TH, int TW, float* __restrict__ V) {
-  const size_t T = (size_t)TH * TW;
+                                                          int TH, int TW, size_t tile0, size_t T,
+                                                          float* __restrict__ V) {
+  // this launch covers tiles [tile0, tile0 + T) of the image; V holds (16, T, C) for them
   const size_t total = T * C4;
   const f32x4* src = reinterpret_cast<const f32x4*>(in);
   f32x4* dst = reinterpret_cast<f32x4*>(V);
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(256) void winograd_in_kernel(const float* __restric
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int c = (int)(e % C4);
     const size_t tile = e / C4;
-    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+    const size_t gt = tile0 + tile;
+    const int tx = (int)(gt % TW), ty = (int)(gt / TW);
     f32x4 d[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -78,10 +80,10 @@ __global__ __launch_bounds__(256) void winograd_in_kernel(const float* __restric
 
 // Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]];  out = relu(Y + bias)  or  (mask > 0 ? Y : 0)
 __global__ __launch_bounds__(256) void winograd_out_kernel(const float* __restrict__ Mw, int H, int W, int C4,
-                                                           int TH, int TW, const float* __restrict__ bias,
+                                                           int TH, int TW, size_t tile0, size_t T,
+                                                           const float* __restrict__ bias,
                                                            const float* __restrict__ mask, int relu,
                                                            float* __restrict__ out) {
-  const size_t T = (size_t)TH * TW;
   const size_t total = T * C4;
   const f32x4* src = reinterpret_cast<const f32x4*>(Mw);
   const f32x4* msk = reinterpret_cast<const f32x4*>(mask);
@@ -89,7 +91,8 @@ __global__ __launch_bounds__(256) void winograd_out_kernel(const float* __restri
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int c = (int)(e % C4);
     const size_t tile = e / C4;
-    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+    const size_t gt = tile0 + tile;
+    const int tx = (int)(gt % TW), ty = (int)(gt / TW);
     f32x4 m[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -127,55 +130,77 @@ __global__ __launch_bounds__(256) void winograd_out_kernel(const float* __restri
   }
 }
 
+// Optional tiling of the tile range into passes whose V and M (16*Tc*(cin+cout) floats) would stay in the
+// 256 MiB Infinity Cache (STROTSS_WINO_CHUNK_MB > 0).  Measured on MI355X: every chunk size tried (48-160 MB)
+// is SLOWER than one pass (more, smaller launches; tails), so the default is 0 = one pass.
+static size_t wino_chunk_tiles(size_t T, int cin, int cout) {
+  static long mb = -1;
+  if (mb < 0) { const char* e = getenv("STROTSS_WINO_CHUNK_MB"); mb = e ? atol(e) : 0; }
+  if (mb == 0) return T;
+  size_t tc = ((size_t)mb << 20) / ((size_t)16 * (cin + cout) * sizeof(float));
+  tc = tc / 128 * 128;
+  if (tc < 1024) tc = 1024;
+  return tc < T ? tc : T;
+}
+
 int winograd_run(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                  const float* mask, int relu, float* out, void* workspace, size_t workspace_bytes,
                  hipStream_t st) {
   const int TH = (h + 1) / 2, TW = (w + 1) / 2;
   const size_t T = (size_t)TH * TW;
+  const size_t Tc = wino_chunk_tiles(T, cin, cout);
   Workspace ws(workspace, workspace_bytes);
-  float* V = ws.take<float>(16 * T * cin * 3 / 2 + 64);      // f32 V, or three bf16 planes (1.5x)
-  float* Mw = ws.take<float>(16 * T * cout);
+  float* V = ws.take<float>(16 * Tc * cin * 3 / 2 + 64);      // f32 V, or three bf16 planes (1.5x)
+  float* Mw = ws.take<float>(16 * Tc * cout);
   unsigned short* Up = ws.take<unsigned short>((size_t)3 * 16 * cout * cin);
   if (!ws.ok()) return STROTSS_EINVAL;
   // EXPERIMENTAL, off by default: STROTSS_MFMA_SPLIT = 6 | 9 runs the 16 GEMMs on the bf16 MFMA by exact
   // 3-way splitting (mfma_split.h); STROTSS_MFMA_SPLIT_APRE = 1 also pre-splits V in the input transform.
-  static int split = -1, apre = 0;
+  static int split = -1, apre = 0, fused = 0;
   if (split < 0) {
     const char* e = getenv("STROTSS_MFMA_SPLIT"); split = e ? atoi(e) : 0;
     const char* a = getenv("STROTSS_MFMA_SPLIT_APRE"); apre = a ? atoi(a) : 0;
+    const char* f = getenv("STROTSS_WINO_FUSED"); fused = f ? atoi(f) : 0;
   }
-  const size_t tin = T * (cin / 4), tout = T * (cout / 4);
-  static int fused = -1;
-  if (fused < 0) { const char* e = getenv("STROTSS_WINO_FUSED"); fused = e ? atoi(e) : 0; }
-  int rc;
+  const bool use_split = split && cout % 128 == 0;
+  if (use_split) {
+    const int rc = st_split_planes(U, (size_t)16 * cout * cin, Up, st);
+    if (rc != 0) return rc;
+  }
   if (fused) {
-    // input transform folded into the GEMM's A loader (V never materialised).  Measured on MI355X:
-    // NOT faster (4x the staging loads, 243 VGPRs -> one wave per SIMD; V is absorbed by the
-    // Infinity Cache anyway), so it is off by default and kept for A/B (STROTSS_WINO_FUSED=1).
-    rc = st_winograd_gemm_fused(in, h, w, cin, TW, (int)T, U, cout, Mw, st);
-  } else {
-    if (split && cout % 128 == 0) {
-      const size_t nU = (size_t)16 * cout * cin, nV = (size_t)16 * T * cin;
-      if (apre)
-        hipLaunchKernelGGL(winograd_in_kernel<true>, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256),
-                           0, st, in, h, w, cin / 4, TH, TW, V);
-      else
-        hipLaunchKernelGGL(winograd_in_kernel<false>, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256),
-                           0, st, in, h, w, cin / 4, TH, TW, V);
-      rc = st_split_planes(U, nU, Up, st);
-      if (rc != 0) return rc;
-      rc = st_gemm_nt_batched_split(V, apre, nV, cin, (long long)T * cin, Up, nU, cin, (long long)cout * cin, Mw,
-                                    cout, (long long)T * cout, (int)T, cout, cin, 16, split, st);
-    } else {
-      hipLaunchKernelGGL(winograd_in_kernel<false>, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0,
-                         st, in, h, w, cin / 4, TH, TW, V);
-      rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
-                              (long long)T * cout, (int)T, cout, cin, 16, st);
-    }
+    // input transform folded into the GEMM's A loader (V never materialised).  Measured on MI355X: NOT
+    // faster (4x the staging loads, 243 VGPRs -> one wave per SIMD), kept for A/B only; single pass.
+    float* Mfull = Mw;
+    if (Tc < T) return STROTSS_EINVAL;     // needs STROTSS_WINO_CHUNK_MB=0
+    int rc = st_winograd_gemm_fused(in, h, w, cin, TW, (int)T, U, cout, Mfull, st);
+    if (rc != 0) return rc;
+    const size_t tout = T * (cout / 4);
+    hipLaunchKernelGGL(winograd_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
+                       Mfull, h, w, cout / 4, TH, TW, (size_t)0, T, bias, mask, relu, out);
+    ST_LAUNCH_RET();
   }
-  if (rc != 0) return rc;
-  hipLaunchKernelGGL(winograd_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
-                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out);
+  for (size_t t0 = 0; t0 < T; t0 += Tc) {
+    const size_t tc = (T - t0 < Tc) ? T - t0 : Tc;
+    const size_t tin = tc * (cin / 4), tout = tc * (cout / 4);
+    const dim3 gin((unsigned)min((size_t)16384, (tin + 255) / 256)), gout((unsigned)min((size_t)16384, (tout + 255) / 256));
+    int rc;
+    if (use_split) {
+      if (apre)
+        hipLaunchKernelGGL(winograd_in_kernel<true>, gin, dim3(256), 0, st, in, h, w, cin / 4, TH, TW, t0, tc, V);
+      else
+        hipLaunchKernelGGL(winograd_in_kernel<false>, gin, dim3(256), 0, st, in, h, w, cin / 4, TH, TW, t0, tc, V);
+      rc = st_gemm_nt_batched_split(V, apre, (size_t)16 * tc * cin, cin, (long long)tc * cin, Up,
+                                    (size_t)16 * cout * cin, cin, (long long)cout * cin, Mw, cout,
+                                    (long long)tc * cout, (int)tc, cout, cin, 16, split, st);
+    } else {
+      hipLaunchKernelGGL(winograd_in_kernel<false>, gin, dim3(256), 0, st, in, h, w, cin / 4, TH, TW, t0, tc, V);
+      rc = st_gemm_nt_batched(V, cin, (long long)tc * cin, U, cin, (long long)cout * cin, Mw, cout,
+                              (long long)tc * cout, (int)tc, cout, cin, 16, st);
+    }
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(winograd_out_kernel, gout, dim3(256), 0, st, Mw, h, w, cout / 4, TH, TW, t0, tc, bias, mask, relu,
+                       out);
+  }
   ST_LAUNCH_RET();
 }
 

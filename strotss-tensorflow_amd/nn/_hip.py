@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstrotss_hip.so")
+LIB_PATH = os.environ.get("STROTSS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libstrotss_hip.so")
 
 MAX_MAPS, MAX_DIVS, MAX_TENSORS = 12, 8, 8
 

@@ -96,10 +96,11 @@ struct ConvALoader {   // A(pixel, k) = in[pixel + tap offset][ci]; out-of-image
   const float* in;
   int base[Cfg::NA];
   unsigned tapmask[Cfg::NA];
-  f32x4 r[Cfg::NA];
-  unsigned okbits;
+  f32x4 r[2][Cfg::NA];
+  unsigned okbits[2];
   int tap, ci0, off, Cin, W;
-  __device__ __forceinline__ ConvALoader(const float* in_, int H, int W_, int Cin_, int m0) : in(in_), okbits(0), tap(0), ci0(0), Cin(Cin_), W(W_) {
+  __device__ __forceinline__ ConvALoader(const float* in_, int H, int W_, int Cin_, int m0) : in(in_), tap(0), ci0(0), Cin(Cin_), W(W_) {
+    okbits[0] = okbits[1] = 0;
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
     const int HW = H * W_;
 #pragma unroll
@@ -121,14 +122,14 @@ struct ConvALoader {   // A(pixel, k) = in[pixel + tap offset][ci]; out-of-image
     }
     off = (-W_ - 1) * Cin_;
   }
-  __device__ __forceinline__ void issue(int i) {
+  __device__ __forceinline__ void issue(int i, int slot) {
     const bool ok = (tapmask[i] >> tap) & 1u;
-    r[i] = *reinterpret_cast<const f32x4*>(in + (ok ? base[i] + off : base[i]));
-    okbits = (okbits & ~(1u << i)) | ((unsigned)ok << i);
+    r[slot][i] = *reinterpret_cast<const f32x4*>(in + (ok ? base[i] + off : base[i]));
+    okbits[slot] = (okbits[slot] & ~(1u << i)) | ((unsigned)ok << i);
   }
-  __device__ __forceinline__ f32x4 value(int i) const {
+  __device__ __forceinline__ f32x4 value(int i, int slot) const {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    return ((okbits >> i) & 1u) ? r[i] : z4;
+    return ((okbits[slot] >> i) & 1u) ? r[slot][i] : z4;
   }
   __device__ __forceinline__ void advance() {
     ci0 += 32; off += 32;
@@ -143,15 +144,15 @@ template <class Cfg>
 struct ConvBLoader {   // B(co, k) = wt[tap][co][ci]
   const float* wt;
   int base[Cfg::NB];
-  f32x4 r[Cfg::NB];
+  f32x4 r[2][Cfg::NB];
   int tap, ci0, off, Cin, CoutCin;
   __device__ __forceinline__ ConvBLoader(const float* wt_, int Cin_, int Cout, int n0) : wt(wt_), tap(0), ci0(0), off(0), Cin(Cin_), CoutCin(Cout * Cin_) {
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 #pragma unroll
     for (int i = 0; i < Cfg::NB; ++i) base[i] = (n0 + r0 + Cfg::RPP * i) * Cin_ + c4 * 4;
   }
-  __device__ __forceinline__ void issue(int i) { r[i] = *reinterpret_cast<const f32x4*>(wt + base[i] + off); }
-  __device__ __forceinline__ f32x4 value(int i) const { return r[i]; }
+  __device__ __forceinline__ void issue(int i, int slot) { r[slot][i] = *reinterpret_cast<const f32x4*>(wt + base[i] + off); }
+  __device__ __forceinline__ f32x4 value(int i, int slot) const { return r[slot][i]; }
   __device__ __forceinline__ void advance() {
     ci0 += 32; off += 32;
     if (ci0 == Cin) { ci0 = 0; ++tap; if (tap == 9) tap = 0; off = tap * CoutCin; }
@@ -166,7 +167,9 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_pipe_kernel(const float*
                                                                     float* __restrict__ out, int relu) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   const int HW = H * W;
-  const int m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  const unsigned gx = Cout / Cfg::BN;                       // 1-D launch, XCD-aware tile order (N-tile fastest)
+  const unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (tile / gx) * Cfg::BM, n0 = (tile % gx) * Cfg::BN;
   ConvALoader<Cfg> la(in, H, W, Cin, m0);
   ConvBLoader<Cfg> lb(wt, Cin, Cout, n0);
   f32x16 acc[Cfg::TM][Cfg::TN];
@@ -237,17 +240,18 @@ int launch_conv(const float* in, int H, int W, int Cin, const float* wt, const f
                        mask, out, relu);
     ST_LAUNCH_RET();
   }
+  const dim3 grid1(grid.x * grid.y);
   if constexpr (BM == 128) {
     if (conv_waves() == 8) {
       using Cfg = PipeCfg<BM, BN, (BN == 128 ? 2 : 4), (BN == 128 ? 4 : 2)>;
-      hipLaunchKernelGGL((conv3x3_mfma_pipe_kernel<Cfg>), grid, dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, bias, Cout,
+      hipLaunchKernelGGL((conv3x3_mfma_pipe_kernel<Cfg>), grid1, dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, bias, Cout,
                          mask, out, relu);
       ST_LAUNCH_RET();
     }
   }
   {
     using Cfg = PipeCfg<BM, BN, 2, 2>;
-    hipLaunchKernelGGL((conv3x3_mfma_pipe_kernel<Cfg>), grid, dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, bias, Cout,
+    hipLaunchKernelGGL((conv3x3_mfma_pipe_kernel<Cfg>), grid1, dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, bias, Cout,
                        mask, out, relu);
   }
   ST_LAUNCH_RET();

@@ -74,7 +74,7 @@ struct EpiMomentFwd {
   }
   __device__ __forceinline__ void finish(float* red, float local) const {
     const float s = block_sum_256(local, red);
-    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s;
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s;   // (two-barrier kernel: 2-D grid)
   }
 };
 // self_similarity backward: dX[i,d] += g * r_i * (acc - xhat[i,d] * q_i), xhat = x * r_i
@@ -121,10 +121,14 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kc_pipe_kernel(const float* __re
                                                                long long strideA, const float* __restrict__ B,
                                                                int ldb, int N, long long strideB, int K, Epi epi) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  A += (long long)blockIdx.z * strideA;
-  B += (long long)blockIdx.z * strideB;
-  epi.set_batch(blockIdx.z);
-  const int m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  // 1-D launch, XCD-aware tile order: N-tile fastest, then M-tile, then batch
+  const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
+  const unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned bz = tile / (gx * gy), rem = tile - bz * (gx * gy);
+  A += (long long)bz * strideA;
+  B += (long long)bz * strideB;
+  epi.set_batch(bz);
+  const int m0 = (rem / gx) * Cfg::BM, n0 = (rem % gx) * Cfg::BN;
   RowMajorLoader<Cfg, Cfg::NA> la(A, lda, m0, M, K);
   RowMajorLoader<Cfg, Cfg::NB> lb(B, ldb, n0, N, K);
   f32x16 acc[Cfg::TM][Cfg::TN];
@@ -146,105 +150,6 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kc_pipe_kernel(const float* __re
         local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
   __syncthreads();
   epi.finish(lds, local);
-}
-
-// Winograd F(2x2,3x3) A-operand computed on the fly: row = tile (ty,tx), position p = (xi,nu) fixed
-// per block; V[p][tile][ci] = sum over the 2x2 input pixels that B^T d B combines for (xi,nu), with
-// signs.  The 4 raw loads per staged row are issued one K-step ahead; zero padding and the +- sums
-// happen at the LDS store.  Saves writing and re-reading the (16, T, Cin) transform tensor.
-template <class Cfg>
-struct WinogradALoader {
-  const float* in;
-  int base[Cfg::NA];            // element offset of pixel (2ty-1, 2tx-1), channel 4*c4 (may be negative)
-  unsigned okbits[Cfg::NA];     // bit (2a+b): pixel (rr[a], cc[b]) of the patch is inside the image
-  f32x4 raw[Cfg::NA][4];
-  int delta[4];                 // uniform: (rr[a]*W + cc[b]) * C
-  float sign[4];                // uniform: sr[a]*sc[b]
-  int k0, C;
-  __device__ __forceinline__ WinogradALoader(const float* in_, int H, int W, int C_, int TW, int T, int pos, int m0)
-      : in(in_), k0(0), C(C_) {
-    const int xi = pos >> 2, nu = pos & 3;
-    // B^T rows: (d0-d2), (d1+d2), (d2-d1), (d1-d3)  ->  the two taps and their signs
-    const int rr0 = (xi == 0) ? 0 : 1, rr1 = (xi == 0) ? 2 : (xi == 3 ? 3 : 2);
-    const float sr0 = (xi == 2) ? -1.f : 1.f, sr1 = (xi == 0 || xi == 3) ? -1.f : 1.f;
-    const int cc0 = (nu == 0) ? 0 : 1, cc1 = (nu == 0) ? 2 : (nu == 3 ? 3 : 2);
-    const float sc0 = (nu == 2) ? -1.f : 1.f, sc1 = (nu == 0 || nu == 3) ? -1.f : 1.f;
-    const int rr[2] = {rr0, rr1}, cc[2] = {cc0, cc1};
-    const float sr[2] = {sr0, sr1}, sc[2] = {sc0, sc1};
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) { delta[2 * a + b] = (rr[a] * W + cc[b]) * C_; sign[2 * a + b] = sr[a] * sc[b]; }
-    const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
-#pragma unroll
-    for (int i = 0; i < Cfg::NA; ++i) {
-      const int tile = m0 + r0 + Cfg::RPP * i;
-      unsigned bits = 0;
-      int bs = 0;
-      if (tile < T) {
-        const int ty = tile / TW, tx = tile - ty * TW;
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-        bs = (y0 * W + x0) * C_ + c4 * 4;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const int y = y0 + rr[a], x = x0 + cc[b];
-            if (y >= 0 && y < H && x >= 0 && x < W) bits |= 1u << (2 * a + b);
-          }
-      }
-      base[i] = bs;
-      okbits[i] = bits;
-    }
-  }
-  __device__ __forceinline__ void issue(int i) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bool ok = (okbits[i] >> q) & 1u;
-      raw[i][q] = *reinterpret_cast<const f32x4*>(in + (ok ? base[i] + delta[q] : (int)((threadIdx.x & 7) * 4)) + k0);
-    }
-  }
-  __device__ __forceinline__ f32x4 value(int i) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float c = ((okbits[i] >> q) & 1u) ? sign[q] : 0.f;
-      v += c * raw[i][q];
-    }
-    return v;
-  }
-  __device__ __forceinline__ void advance() { k0 += 32; if (k0 >= C) k0 = 0; }
-};
-
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::NT) void winograd_gemm_fused_kernel(const float* __restrict__ in, int H, int W,
-                                                                      int C, int TW, int T,
-                                                                      const float* __restrict__ U, int N,
-                                                                      float* __restrict__ Mw) {
-  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  const int pos = blockIdx.z;
-  const int m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
-  WinogradALoader<Cfg> la(in, H, W, C, TW, T, pos, m0);
-  RowMajorLoader<Cfg, Cfg::NB> lb(U + (size_t)pos * N * C, C, n0, N, C);
-  f32x16 acc[Cfg::TM][Cfg::TN];
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  pipe_mainloop<Cfg>(lds, C >> 5, la, lb, acc);
-  PipeAccMap<Cfg> map;
-  float* out = Mw + (size_t)pos * T * N;
-#pragma unroll
-  for (int im = 0; im < Cfg::TM; ++im)
-#pragma unroll
-    for (int in_ = 0; in_ < Cfg::TN; ++in_)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = m0 + map.row(im, reg), col = n0 + map.colof(in_);
-        if (row < T && col < N) out[(size_t)row * N + col] = acc[im][in_][reg];
-      }
 }
 
 // ---- f32 GEMM on the bf16 MFMA by exact 3-way splitting (mfma_split.h) ---------------------------
@@ -320,7 +225,7 @@ static int gemm_waves() {
 template <int BM, int BN, class Epi>
 int launch_pipe(const float* A, int lda, int M, long long strideA, const float* B, int ldb, int N,
                 long long strideB, int K, int batch, Epi epi, hipStream_t s) {
-  dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
+  dim3 grid((unsigned)cdiv(N, BN) * cdiv(M, BM) * batch);
   if constexpr (BM == 128) {
     if (gemm_waves() == 8) {
       using Cfg = PipeCfg<BM, BN, (BN == 128 ? 2 : 4), (BN == 128 ? 4 : 2)>;
@@ -391,25 +296,6 @@ int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* 
   if ((long long)cdiv(M, 128) * cdiv(N, 64) * batch >= 512)
     return launch_pipe<128, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
   return launch_pipe<64, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
-}
-
-// M[p] (T x N) = (B^T d B)[p] (T x C, computed on the fly from in(H,W,C)) * U[p]^T (N x C), p = 0..15
-int st_winograd_gemm_fused(const float* in, int H, int W, int C, int TW, int T, const float* U, int N, float* Mw,
-                           hipStream_t s) {
-  if ((long long)cdiv(T, 128) * cdiv(N, 128) * 16 >= 512 && N % 128 == 0) {
-    using Cfg = PipeCfg<128, 128, 2, 2>;
-    hipLaunchKernelGGL((winograd_gemm_fused_kernel<Cfg>), dim3(cdiv(N, 128), cdiv(T, 128), 16), dim3(Cfg::NT), 0, s,
-                       in, H, W, C, TW, T, U, N, Mw);
-  } else if ((long long)cdiv(T, 128) * cdiv(N, 64) * 16 >= 512) {
-    using Cfg = PipeCfg<128, 64, 2, 2>;
-    hipLaunchKernelGGL((winograd_gemm_fused_kernel<Cfg>), dim3(cdiv(N, 64), cdiv(T, 128), 16), dim3(Cfg::NT), 0, s,
-                       in, H, W, C, TW, T, U, N, Mw);
-  } else {
-    using Cfg = PipeCfg<64, 64, 2, 2>;
-    hipLaunchKernelGGL((winograd_gemm_fused_kernel<Cfg>), dim3(cdiv(N, 64), cdiv(T, 64), 16), dim3(Cfg::NT), 0, s,
-                       in, H, W, C, TW, T, U, N, Mw);
-  }
-  ST_LAUNCH_RET();
 }
 
 int st_split_planes(const float* x, size_t n, void* planes, hipStream_t s) {

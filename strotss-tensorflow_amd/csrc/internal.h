@@ -16,9 +16,6 @@ int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, cons
 int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                        float* C, int ldc, long long strideC, int M, int N, int K, int batch, hipStream_t s);
 
-int st_winograd_gemm_fused(const float* in, int H, int W, int C, int TW, int T, const float* U, int N, float* Mw,
-                           hipStream_t s);
-
 int st_split_planes(const float* x, size_t n, void* planes, hipStream_t s);
 int st_gemm_nt_batched_split(const void* A, int a_pre, size_t a_plane_stride, int lda, long long strideA,
                              const void* Bp, size_t b_plane_stride, int ldb, long long strideB, float* C, int ldc,

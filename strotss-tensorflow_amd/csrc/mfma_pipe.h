@@ -12,14 +12,27 @@
 //     64-cycle f32 MFMAs.  Loads are branch-free (clamped address); rows/taps outside the operand
 //     are zeroed at the LDS store one step later, so no load is waited for at issue.
 //
-// Loader protocol (functor L, owns its staging registers):
-//   L.issue(i)  : issue the raw 16-byte load(s) of staged row i of the NEXT tile (no use of the data);
-//   L.value(i)  : the f32x4 to put in LDS for row i of the tile issued ONE step earlier (this is where
-//                 out-of-range rows/taps become zeros and where fused transforms combine their loads);
-//   L.advance() : move to the following tile; loads past the last tile must stay in bounds (wrap) --
-//                 their data is never used.
+// Global loads run TWO K-steps ahead of the LDS store that consumes them (two register slots; measured:
+// removing the loads altogether is worth 18 %, i.e. their latency was exposed at distance one).
+// Loader protocol (functor L, owns its staging registers, two slots):
+//   L.issue(i, slot) : issue the raw 16-byte load of staged row i of the NEXT tile into `slot`;
+//   L.value(i, slot) : the f32x4 to put in LDS for row i of the tile held in `slot` (this is where
+//                      out-of-range rows/taps become zeros);
+//   L.advance()      : move to the following tile; loads past the last tile must stay in bounds
+//                      (wrap) -- their data is never used.
 #pragma once
+#include <type_traits>
+
 #include "mfma_tile.h"
+
+// XCD-aware workgroup id (guide T1): hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs (each with a private 4 MiB L2).  Remap so that every XCD owns a CONTIGUOUS range of the logical
+// tile order -- neighbouring tiles (same A panel, adjacent B panels, halo rows) then share an L2.
+// Bijective for any workgroup count.  Speed only: results do not depend on placement.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned id, unsigned n) {
+  const unsigned xcd = id & 7u, slot = id >> 3, q = n >> 3, r = n & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
 
 template <int BM_, int BN_, int WM_, int WN_>
 struct PipeCfg {
@@ -52,29 +65,28 @@ __device__ __forceinline__ void pipe_mainloop(float* lds, int steps, LA& la, LB&
   const int t = threadIdx.x, c4 = t & 7, r0 = t >> 3;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN, l31 = lane & 31, hh = lane >> 5;
-  auto load_a = [&](int i) { la.issue(i); };
-  auto load_b = [&](int i) { lb.issue(i); };
-  auto store_a = [&](float* buf, int i) {
-    *reinterpret_cast<f32x4*>(&buf[(r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = la.value(i);
+  auto store_a = [&](float* buf, int i, int slot) {
+    *reinterpret_cast<f32x4*>(&buf[(r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = la.value(i, slot);
   };
-  auto store_b = [&](float* buf, int i) {
-    *reinterpret_cast<f32x4*>(&buf[A_FL + (r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = lb.value(i);
+  auto store_b = [&](float* buf, int i, int slot) {
+    *reinterpret_cast<f32x4*>(&buf[A_FL + (r0 + Cfg::RPP * i) * KC_LD + c4 * 4]) = lb.value(i, slot);
   };
-  // prologue: tile 0 -> buffer 0, tile 1 -> registers
+  auto issue_tile = [&](int slot) {
 #pragma unroll
-  for (int i = 0; i < NA; ++i) load_a(i);
+    for (int i = 0; i < NA; ++i) la.issue(i, slot);
 #pragma unroll
-  for (int i = 0; i < NB; ++i) load_b(i);
-  la.advance(); lb.advance();
+    for (int i = 0; i < NB; ++i) lb.issue(i, slot);
+    la.advance(); lb.advance();
+  };
+  // prologue: tile 0 -> LDS buffer 0; tile 1 -> register slot 1; tile 2 -> register slot 0.
+  // (the global loads run TWO K-steps ahead of the LDS store that consumes them)
+  issue_tile(0);
 #pragma unroll
-  for (int i = 0; i < NA; ++i) store_a(lds, i);
+  for (int i = 0; i < NA; ++i) store_a(lds, i, 0);
 #pragma unroll
-  for (int i = 0; i < NB; ++i) store_b(lds, i);
-#pragma unroll
-  for (int i = 0; i < NA; ++i) load_a(i);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) load_b(i);
-  la.advance(); lb.advance();
+  for (int i = 0; i < NB; ++i) store_b(lds, i, 0);
+  issue_tile(1);
+  issue_tile(0);
   __syncthreads();
 
   const int arow = (wm * (Cfg::BM / Cfg::WM) + l31) * KC_LD + 4 * hh;
@@ -84,9 +96,10 @@ __device__ __forceinline__ void pipe_mainloop(float* lds, int steps, LA& la, LB&
   for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(&lds[arow + i * 32 * KC_LD]);
 #pragma unroll
   for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f32x4*>(&lds[brow + i * 32 * KC_LD]);
-  for (int s = 0; s < steps; ++s) {
-    const float* cur = lds + (s & 1) * (A_FL + B_FL);
-    float* nxt = lds + ((s + 1) & 1) * (A_FL + B_FL);
+
+  // one K-step: MFMAs on `cur`; tile s+1 (register slot SLOT) -> `nxt`; tile s+3 -> register slot SLOT
+  auto kstep = [&](const float* cur, float* nxt, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (g < 3) {
@@ -108,13 +121,13 @@ __device__ __forceinline__ void pipe_mainloop(float* lds, int steps, LA& la, LB&
         if (j == 0) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = g; i < NA; i += 4) { store_a(nxt, i); load_a(i); }
+          for (int i = g; i < NA; i += 4) { store_a(nxt, i, SLOT); la.issue(i, SLOT); }
           __builtin_amdgcn_sched_barrier(0);
         }
         if (j == 1) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = g; i < NB; i += 4) { store_b(nxt, i); load_b(i); }
+          for (int i = g; i < NB; i += 4) { store_b(nxt, i, SLOT); lb.issue(i, SLOT); }
           __builtin_amdgcn_sched_barrier(0);
           if (g == 3) {
             __syncthreads();
@@ -128,7 +141,15 @@ __device__ __forceinline__ void pipe_mainloop(float* lds, int steps, LA& la, LB&
       }
     }
     la.advance(); lb.advance();
+  };
+  float* buf0 = lds;
+  float* buf1 = lds + (A_FL + B_FL);
+  int s = 0;
+  for (; s + 1 < steps; s += 2) {
+    kstep(buf0, buf1, std::integral_constant<int, 1>{});
+    kstep(buf1, buf0, std::integral_constant<int, 0>{});
   }
+  if (s < steps) kstep(buf0, buf1, std::integral_constant<int, 1>{});
 }
 
 // Plain row-major K-contiguous operand: element (row, k) at p[row*ld + k]; rows >= nrows are zeros.
@@ -136,7 +157,7 @@ template <class Cfg, int NROWS_STAGED>
 struct RowMajorLoader {
   const float* p;
   size_t base[NROWS_STAGED];
-  f32x4 r[NROWS_STAGED];
+  f32x4 r[2][NROWS_STAGED];
   unsigned ok;
   int k0, K;
   __device__ __forceinline__ RowMajorLoader(const float* ptr, int ld, int row0, int nrows, int K_) : p(ptr), ok(0), k0(0), K(K_) {
@@ -148,10 +169,10 @@ struct RowMajorLoader {
       base[i] = (size_t)min(row, nrows - 1) * ld + c4 * 4;
     }
   }
-  __device__ __forceinline__ void issue(int i) { r[i] = *reinterpret_cast<const f32x4*>(p + base[i] + k0); }
-  __device__ __forceinline__ f32x4 value(int i) const {
+  __device__ __forceinline__ void issue(int i, int slot) { r[slot][i] = *reinterpret_cast<const f32x4*>(p + base[i] + k0); }
+  __device__ __forceinline__ f32x4 value(int i, int slot) const {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    return ((ok >> i) & 1u) ? r[i] : z4;
+    return ((ok >> i) & 1u) ? r[slot][i] : z4;
   }
   __device__ __forceinline__ void advance() { k0 += 32; if (k0 >= K) k0 = 0; }
 };

@@ -71,12 +71,12 @@ __device__ __forceinline__ void split_mainloop(unsigned char* lds, int steps, LA
 #pragma unroll
       for (int p = 0; p < 3; ++p) la.issue(i, p);
     } else {
-      const Split3 s = split3(la.value(i));
+      const Split3 s = split3(la.value(i, 0));
       const int o = ((t >> 3) + 32 * i) * SP_ROW_BYTES + (t & 7) * 8;
       *reinterpret_cast<bf16x4*>(buf + o) = s.h;
       *reinterpret_cast<bf16x4*>(buf + A_PL + o) = s.m;
       *reinterpret_cast<bf16x4*>(buf + 2 * A_PL + o) = s.l;
-      la.issue(i);
+      la.issue(i, 0);
     }
   };
   auto stage_b = [&](unsigned char* buf, int i) {
@@ -88,12 +88,12 @@ __device__ __forceinline__ void split_mainloop(unsigned char* lds, int steps, LA
 #pragma unroll
       for (int p = 0; p < 3; ++p) lb.issue(i, p);
     } else {
-      const Split3 s = split3(lb.value(i));
+      const Split3 s = split3(lb.value(i, 0));
       const int o = ((t >> 3) + 32 * i) * SP_ROW_BYTES + (t & 7) * 8;
       *reinterpret_cast<bf16x4*>(b + o) = s.h;
       *reinterpret_cast<bf16x4*>(b + B_PL + o) = s.m;
       *reinterpret_cast<bf16x4*>(b + 2 * B_PL + o) = s.l;
-      lb.issue(i);
+      lb.issue(i, 0);
     }
   };
   auto issue_all = [&]() {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void split_mainloop(unsigned char* lds, int steps, LA
 #pragma unroll
         for (int p = 0; p < 3; ++p) la.issue(i, p);
       } else {
-        la.issue(i);
+        la.issue(i, 0);
       }
     }
 #pragma unroll
@@ -112,7 +112,7 @@ __device__ __forceinline__ void split_mainloop(unsigned char* lds, int steps, LA
 #pragma unroll
         for (int p = 0; p < 3; ++p) lb.issue(i, p);
       } else {
-        lb.issue(i);
+        lb.issue(i, 0);
       }
     }
   };

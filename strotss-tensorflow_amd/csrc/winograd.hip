@@ -156,28 +156,15 @@ int winograd_run(const float* in, int h, int w, int cin, const float* U, const f
   if (!ws.ok()) return STROTSS_EINVAL;
   // EXPERIMENTAL, off by default: STROTSS_MFMA_SPLIT = 6 | 9 runs the 16 GEMMs on the bf16 MFMA by exact
   // 3-way splitting (mfma_split.h); STROTSS_MFMA_SPLIT_APRE = 1 also pre-splits V in the input transform.
-  static int split = -1, apre = 0, fused = 0;
+  static int split = -1, apre = 0;
   if (split < 0) {
     const char* e = getenv("STROTSS_MFMA_SPLIT"); split = e ? atoi(e) : 0;
     const char* a = getenv("STROTSS_MFMA_SPLIT_APRE"); apre = a ? atoi(a) : 0;
-    const char* f = getenv("STROTSS_WINO_FUSED"); fused = f ? atoi(f) : 0;
   }
   const bool use_split = split && cout % 128 == 0;
   if (use_split) {
     const int rc = st_split_planes(U, (size_t)16 * cout * cin, Up, st);
     if (rc != 0) return rc;
-  }
-  if (fused) {
-    // input transform folded into the GEMM's A loader (V never materialised).  Measured on MI355X: NOT
-    // faster (4x the staging loads, 243 VGPRs -> one wave per SIMD), kept for A/B only; single pass.
-    float* Mfull = Mw;
-    if (Tc < T) return STROTSS_EINVAL;     // needs STROTSS_WINO_CHUNK_MB=0
-    int rc = st_winograd_gemm_fused(in, h, w, cin, TW, (int)T, U, cout, Mfull, st);
-    if (rc != 0) return rc;
-    const size_t tout = T * (cout / 4);
-    hipLaunchKernelGGL(winograd_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
-                       Mfull, h, w, cout / 4, TH, TW, (size_t)0, T, bias, mask, relu, out);
-    ST_LAUNCH_RET();
   }
   for (size_t t0 = 0; t0 < T; t0 += Tc) {
     const size_t tc = (T - t0 < Tc) ? T - t0 : Tc;

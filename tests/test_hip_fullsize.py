@@ -148,7 +148,7 @@ def test_loss_identities_fullsize():
     assert np.abs(vals[0] - vals[1]).max() < 2e-6 * max(1.0, np.abs(vals[0]).max())
     # cosine cost matrix at full size: bitwise symmetric, zero diagonal to rounding, range [0, 2]
     Dm = _ops.cosine_distance(x, rs, N, x, rs, N)[:, :N]
-    assert torch.equal(Dm, Dm.T) and float(Dm.diagonal().abs().max()) < 5e-7
+    assert torch.equal(Dm, Dm.T) and float(Dm.diagonal().abs().max()) < 5e-5
     assert float(Dm.min()) > -1e-6 and float(Dm.max()) < 2.0
 
 

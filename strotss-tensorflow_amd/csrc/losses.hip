@@ -113,28 +113,48 @@ __global__ __launch_bounds__(256) void row_min_kernel(const float* __restrict__ 
   c = block_sum_256(c, red);
   if (threadIdx.x == 0) { rmin[blockIdx.x] = m; rcnt[blockIdx.x] = c; }
 }
-// cmin[j] = min_i C[i,j], ccnt[j] = #{i : C[i,j] == cmin[j]};  64 columns per block
-__global__ __launch_bounds__(256) void col_min_kernel(const float* __restrict__ C, int ns, int n, int ldc,
-                                                      float* __restrict__ cmin, float* __restrict__ ccnt) {
+// cmin[j] = min_i C[i,j], ccnt[j] = #{i : C[i,j] == cmin[j]} in two stages so that the column reduction
+// uses the whole chip: stage 1 reduces COL_CHUNKS row chunks (grid (n/64, COL_CHUNKS)) to a local
+// (min, count-of-min) per column, stage 2 combines them (count = sum over the chunks that attain the
+// global min).  Fixed order -> bitwise reproducible.
+#define COL_CHUNKS 16
+__global__ __launch_bounds__(256) void col_min_partial_kernel(const float* __restrict__ C, int ns, int n, int ldc,
+                                                              float* __restrict__ pmin, float* __restrict__ pcnt) {
   __shared__ float sm[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
+  const int per = (ns + COL_CHUNKS - 1) / COL_CHUNKS;
+  const int i0 = blockIdx.y * per, i1 = min(ns, i0 + per);
   float m = INFINITY;
   if (j < n)
-    for (int i = g; i < ns; i += 4) m = fminf(m, C[(size_t)i * ldc + j]);
+    for (int i = i0 + g; i < i1; i += 4) m = fminf(m, C[(size_t)i * ldc + j]);
   sm[g][c] = m;
   __syncthreads();
   m = fminf(fminf(sm[0][c], sm[1][c]), fminf(sm[2][c], sm[3][c]));
   __syncthreads();
   float cnt = 0.f;
   if (j < n)
-    for (int i = g; i < ns; i += 4) cnt += (C[(size_t)i * ldc + j] == m) ? 1.f : 0.f;
+    for (int i = i0 + g; i < i1; i += 4) cnt += (C[(size_t)i * ldc + j] == m) ? 1.f : 0.f;
   sm[g][c] = cnt;
   __syncthreads();
   if (g == 0 && j < n) {
-    cmin[j] = m;
-    ccnt[j] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    pmin[(size_t)blockIdx.y * ldc + j] = m;
+    pcnt[(size_t)blockIdx.y * ldc + j] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
   }
+}
+__global__ __launch_bounds__(256) void col_min_final_kernel(const float* __restrict__ pmin,
+                                                            const float* __restrict__ pcnt, int n, int ldc,
+                                                            float* __restrict__ cmin, float* __restrict__ ccnt) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float m = INFINITY;
+#pragma unroll
+  for (int k = 0; k < COL_CHUNKS; ++k) m = fminf(m, pmin[(size_t)k * ldc + j]);
+  float cnt = 0.f;
+#pragma unroll
+  for (int k = 0; k < COL_CHUNKS; ++k) cnt += (pmin[(size_t)k * ldc + j] == m) ? pcnt[(size_t)k * ldc + j] : 0.f;
+  cmin[j] = m;
+  ccnt[j] = cnt;
 }
 // loss = max(mean rmin, mean cmin); sel[0] = 1 when the row branch carries the gradient
 // (tf.maximum: first argument on ties).
@@ -295,18 +315,30 @@ __global__ __launch_bounds__(64) void palette_bwd_kernel(
 }
 
 // ---------------------------------------------------------------- moment matching helpers
-// mean[c] = (1/n) sum_{i<n} y[i,c];  64 columns per block
-__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ y, int n, int ld,
-                                                       float* __restrict__ mean) {
+// mean[c] = (1/n) sum_{i<n} y[i,c] in two stages (grid (ld/64, COL_CHUNKS) partial sums, then a fixed-order
+// combine), so the column reduction uses the whole chip.
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ y, int n, int ld,
+                                                              float* __restrict__ psum) {
   __shared__ float sm[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + c;
+  const int per = (n + COL_CHUNKS - 1) / COL_CHUNKS;
+  const int i0 = blockIdx.y * per, i1 = min(n, i0 + per);
   float a = 0.f;
   if (col < ld)
-    for (int i = g; i < n; i += 4) a += y[(size_t)i * ld + col];
+    for (int i = i0 + g; i < i1; i += 4) a += y[(size_t)i * ld + col];
   sm[g][c] = a;
   __syncthreads();
-  if (g == 0 && col < ld) mean[col] = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) / (float)n;
+  if (g == 0 && col < ld) psum[(size_t)blockIdx.y * ld + col] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+}
+__global__ __launch_bounds__(256) void col_mean_final_kernel(const float* __restrict__ psum, int n, int ld,
+                                                             float* __restrict__ mean) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ld) return;
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < COL_CHUNKS; ++k) a += psum[(size_t)k * ld + col];
+  mean[col] = a / (float)n;
 }
 // cy[i,c] = y[i,c] - mean[c] for i < n, 0 for n <= i < rows
 __global__ __launch_bounds__(256) void center_kernel(const float* __restrict__ y, int n, int rows, int ld,
@@ -370,7 +402,7 @@ struct SelfsimWs {
   }
 };
 struct RemdWs {
-  float *rp, *C, *rmin, *rcnt, *cmin, *ccnt;
+  float *rp, *C, *rmin, *rcnt, *cmin, *ccnt, *pmin, *pcnt;
   f32x4 *ys, *yp;
   int* sel;
   int ldc;
@@ -380,13 +412,14 @@ struct RemdWs {
     C = w.take<float>((size_t)ns * ldc);
     rmin = w.take<float>(ns); rcnt = w.take<float>(ns);
     cmin = w.take<float>(ldc); ccnt = w.take<float>(ldc);
+    pmin = w.take<float>((size_t)COL_CHUNKS * ldc); pcnt = w.take<float>((size_t)COL_CHUNKS * ldc);
     ys = w.take<f32x4>(ns); yp = w.take<f32x4>(n);
     sel = w.take<int>(4);
     return w.ok();
   }
 };
 struct MomentWs {
-  float *mean, *cy, *T, *partial, *sgn;
+  float *mean, *cy, *T, *partial, *sgn, *psum;
   int rows;
   bool plan(Workspace& w, int n, int ld) {
     rows = round_up(n, 32);
@@ -395,6 +428,7 @@ struct MomentWs {
     T = w.take<float>((size_t)ld * ld);
     partial = w.take<float>((size_t)cdiv(ld, 64) * cdiv(ld, 64));
     sgn = w.take<float>(ld);
+    psum = w.take<float>((size_t)COL_CHUNKS * ld);
     return w.ok();
   }
 };
@@ -474,7 +508,10 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   LAUNCH_OK();
   CHK(st_cosine_distance(style, rs, ns, pred, s.rp, n, ld, s.C, ldc, st));
   hipLaunchKernelGGL(row_min_kernel, dim3(ns), dim3(256), 0, st, s.C, n, ldc, s.rmin, s.rcnt);
-  hipLaunchKernelGGL(col_min_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, s.C, ns, n, ldc, s.cmin, s.ccnt);
+  hipLaunchKernelGGL(col_min_partial_kernel, dim3(cdiv(n, 64), COL_CHUNKS), dim3(256), 0, st, s.C, ns, n, ldc, s.pmin,
+                     s.pcnt);
+  hipLaunchKernelGGL(col_min_final_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, s.pmin, s.pcnt, n, ldc, s.cmin,
+                     s.ccnt);
   hipLaunchKernelGGL(remd_select_kernel, dim3(1), dim3(256), 0, st, s.rmin, ns, s.cmin, n, loss_out, s.sel);
   hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldc, style, rs, ns, pred, s.rp, n,
                      ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
@@ -495,7 +532,10 @@ int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, 
   hipLaunchKernelGGL(palette_cost_kernel, dim3(cdiv(n, 256), ns), dim3(256), 0, st, s.ys, ns, s.yp, n, s.C,
                      ldc);
   hipLaunchKernelGGL(row_min_kernel, dim3(ns), dim3(256), 0, st, s.C, n, ldc, s.rmin, s.rcnt);
-  hipLaunchKernelGGL(col_min_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, s.C, ns, n, ldc, s.cmin, s.ccnt);
+  hipLaunchKernelGGL(col_min_partial_kernel, dim3(cdiv(n, 64), COL_CHUNKS), dim3(256), 0, st, s.C, ns, n, ldc, s.pmin,
+                     s.pcnt);
+  hipLaunchKernelGGL(col_min_final_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, s.pmin, s.pcnt, n, ldc, s.cmin,
+                     s.ccnt);
   hipLaunchKernelGGL(remd_select_kernel, dim3(1), dim3(256), 0, st, s.rmin, ns, s.cmin, n, loss_out, s.sel);
   hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, s.C, ldc, s.ys, ns, s.yp, n, s.rmin,
                      s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred, ld, rgb_to_yuv);
@@ -517,7 +557,8 @@ int strotss_moment_stats(const float* x, int n, int d, int ld, float* mean_out, 
   MomentWs s;
   ST_CHECK_ARG(s.plan(w, n, ld), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(col_mean_kernel, dim3(cdiv(ld, 64)), dim3(256), 0, st, x, n, ld, mean_out);
+  hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(ld, 64), COL_CHUNKS), dim3(256), 0, st, x, n, ld, s.psum);
+  hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, st, s.psum, n, ld, mean_out);
   hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st, x,
                      n, s.rows, ld, mean_out, s.cy);
   LAUNCH_OK();
@@ -534,7 +575,8 @@ int strotss_moment_fwd_bwd(const float* style_mean, const float* style_cov, cons
   MomentWs s;
   ST_CHECK_ARG(s.plan(w, n, ld), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(col_mean_kernel, dim3(cdiv(ld, 64)), dim3(256), 0, st, pred, n, ld, s.mean);
+  hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(ld, 64), COL_CHUNKS), dim3(256), 0, st, pred, n, ld, s.psum);
+  hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, st, s.psum, n, ld, s.mean);
   hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st,
                      pred, n, s.rows, ld, s.mean, s.cy);
   LAUNCH_OK();

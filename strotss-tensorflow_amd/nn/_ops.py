@@ -125,7 +125,8 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
 def winograd_weights(g: torch.Tensor) -> torch.Tensor:
     """g: (N, K, 3, 3) kernel as [out-channel][in-channel][r][q] (float64 on the host) ->
     U (16, N, K) float32 with U[4*xi+nu] = (G g G^T)[xi, nu]."""
-    G = torch.tensor([[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]], dtype=torch.float64)
+    G = torch.tensor([[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]], dtype=torch.float64,
+                     device=g.device)
     u = torch.einsum("ar,nkrq,bq->abnk", G, g.double(), G)
     return u.reshape(16, g.shape[0], g.shape[1]).float().contiguous()
 

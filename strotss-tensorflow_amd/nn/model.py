@@ -121,7 +121,7 @@ class VGGParams:
             w, b = weights[li]
             li += 1
             assert tuple(w.shape) == (3, 3, cin, cout), (name, tuple(w.shape))
-            w = w.float()
+            w = w.float().to(device)          # re-layouts below run on the device (once per model)
             if use_keras_weight and cin == 3:
                 w = w.flip(2)
             L = {"name": name, "cin": cin, "cout": cout, "bias": b.float().contiguous().to(device)}

@@ -311,3 +311,32 @@ def test_cli_with_masks(tmp_path):
                                          str(tmp_path / "sm.jpg"), "--level", "2", "--max_iter", "3"])
     final = RS.run(args)
     assert tuple(final.shape) == (102, 128, 3) and os.path.exists(out)
+
+
+def test_cli_config1_reference_images(tmp_path):
+    """BASELINE config 1 on the reference's own two images (data fixtures under tests/golden/):
+    256 px, one scale, 50 RMSprop steps -> `--max_size 256 --start_level 2 --level 3 --max_iter 50`
+    (SURVEY.md 8d mapping).  Checks the size arithmetic of the reference (321x481 -> 170x256), that the
+    optimisation makes progress and that a JPEG comes out."""
+    from PIL import Image
+    import run_strotss as RS
+    from nn import engine as E
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    out = tmp_path / "out.jpg"
+    args = RS.build_parser().parse_args([os.path.join(g, "content_im.jpg"), os.path.join(g, "style_im.jpg"), "-o", str(out),
+                                         "--max_size", "256", "--start_level", "2", "--level", "3", "--max_iter", "50",
+                                         "--log_every", "50"])
+    seen = []
+    orig = E.StepEngine.losses
+
+    def spy(self):
+        r = orig(self); seen.append((self.steps_done, r["loss"])); return r
+    E.StepEngine.losses = spy
+    try:
+        final = RS.run(args)
+    finally:
+        E.StepEngine.losses = orig
+    assert tuple(final.shape) == (170, 256, 3) and final.dtype == torch.uint8
+    assert seen and seen[-1][0] == 50 and np.isfinite(seen[-1][1])
+    with Image.open(out) as im:
+        assert im.format == "JPEG" and im.size == (256, 170)

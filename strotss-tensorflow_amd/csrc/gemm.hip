@@ -166,32 +166,33 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 
 
-struct SplitACfg { static constexpr int RPP = 32; };   // f32 staging: 8 lanes per row, 32 rows per pass
-template <bool PRE, class Cfg> struct SplitALoader;
-template <class Cfg> struct SplitALoader<true, Cfg> { using type = PlaneRowLoader<Cfg::NA>; };
-template <class Cfg> struct SplitALoader<false, Cfg> { using type = RowMajorLoader<SplitACfg, Cfg::NA>; };
+template <int R> struct SplitACfg { static constexpr int RPP = R; };   // f32 staging: 8 lanes per row
 
 // B (frozen weights) is pre-split into bf16 planes.  A is either f32 (split at the LDS store, APRE = false)
 // or three bf16 planes written by winograd_in_kernel<true> (APRE = true).
 template <class Cfg, class Epi>
-__global__ __launch_bounds__(256) void gemm_split_kernel(const void* __restrict__ Av, size_t a_plane_stride,
+__global__ __launch_bounds__(Cfg::NT) void gemm_split_kernel(const void* __restrict__ Av, size_t a_plane_stride,
                                                          int lda, int M, long long strideA,
                                                          const __bf16* __restrict__ Bp, size_t b_plane_stride,
                                                          int ldb, int N, long long strideB, int K, Epi epi) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[Cfg::LDS_BYTES];
-  Bp += (long long)blockIdx.z * strideB;
-  epi.set_batch(blockIdx.z);
-  const int m0 = blockIdx.y * Cfg::BM, n0 = blockIdx.x * Cfg::BN;
+  // 1-D launch, XCD-aware tile order: N-tile fastest, then M-tile, then batch
+  const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
+  const unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned bz = tile / (gx * gy), rem = tile - bz * (gx * gy);
+  Bp += (long long)bz * strideB;
+  epi.set_batch(bz);
+  const int m0 = (rem / gx) * Cfg::BM, n0 = (rem % gx) * Cfg::BN;
   auto make_a = [&]() {
     if constexpr (Cfg::APRE)
-      return PlaneRowLoader<Cfg::NA>(reinterpret_cast<const __bf16*>(Av) + (long long)blockIdx.z * strideA,
-                                     a_plane_stride, lda, m0, M, K);
+      return PlaneRowLoader<Cfg::NA, Cfg::RPP_PRE>(reinterpret_cast<const __bf16*>(Av) + (long long)bz * strideA,
+                                                   a_plane_stride, lda, m0, M, K);
     else
-      return RowMajorLoader<SplitACfg, Cfg::NA>(reinterpret_cast<const float*>(Av) + (long long)blockIdx.z * strideA,
-                                                lda, m0, M, K);
+      return RowMajorLoader<SplitACfg<Cfg::RPP_F32>, Cfg::NA>(
+          reinterpret_cast<const float*>(Av) + (long long)bz * strideA, lda, m0, M, K);
   };
   auto la = make_a();
-  PlaneRowLoader<Cfg::NB> lb(Bp, b_plane_stride, ldb, n0, N, K);
+  PlaneRowLoader<Cfg::NB, Cfg::RPP_PRE> lb(Bp, b_plane_stride, ldb, n0, N, K);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const void* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   split_mainloop<Cfg>(lds, K >> 5, la, lb, acc);
-  AccMap<Cfg::BM, Cfg::BN> map;
+  PipeAccMap<Cfg> map;
   float local = 0.f;
 #pragma unroll
   for (int im = 0; im < Cfg::TM; ++im)
@@ -311,10 +312,18 @@ template <bool APRE, int NP>
 static int launch_split(const void* A, size_t a_plane_stride, int lda, long long strideA, const void* Bp,
                         size_t b_plane_stride, int ldb, long long strideB, EpiScaleStore e, int M, int N, int K,
                         int batch, hipStream_t s) {
-  using Cfg = SplitCfg<128, 128, APRE, true, NP>;
-  dim3 grid(cdiv(N, 128), cdiv(M, 128), batch);
-  hipLaunchKernelGGL((gemm_split_kernel<Cfg, EpiScaleStore>), grid, dim3(256), 0, s, A, a_plane_stride, lda, M,
-                     strideA, (const __bf16*)Bp, b_plane_stride, ldb, N, strideB, K, e);
+  dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
+  static int w8 = -1;
+  if (w8 < 0) { const char* ev = getenv("STROTSS_SPLIT_WAVES"); w8 = (ev && atoi(ev) == 8) ? 1 : 0; }
+  if (w8) {
+    using Cfg = SplitCfg<128, 128, APRE, true, NP, 2, 4>;
+    hipLaunchKernelGGL((gemm_split_kernel<Cfg, EpiScaleStore>), grid, dim3(Cfg::NT), 0, s, A, a_plane_stride, lda, M,
+                       strideA, (const __bf16*)Bp, b_plane_stride, ldb, N, strideB, K, e);
+  } else {
+    using Cfg = SplitCfg<128, 128, APRE, true, NP>;
+    hipLaunchKernelGGL((gemm_split_kernel<Cfg, EpiScaleStore>), grid, dim3(Cfg::NT), 0, s, A, a_plane_stride, lda, M,
+                       strideA, (const __bf16*)Bp, b_plane_stride, ldb, N, strideB, K, e);
+  }
   ST_LAUNCH_RET();
 }
 int st_gemm_nt_batched_split(const void* A, int a_pre, size_t a_plane_stride, int lda, long long strideA,

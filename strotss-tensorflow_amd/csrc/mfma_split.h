@@ -24,13 +24,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define SP_ROW_BYTES 80
 
-template <int BM_, int BN_, bool APRE_, bool BPRE_, int NPROD_>
+template <int BM_, int BN_, bool APRE_, bool BPRE_, int NPROD_, int WM_ = 2, int WN_ = 2>
 struct SplitCfg {
-  static constexpr int BM = BM_, BN = BN_, NT = 256, NPROD = NPROD_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NT = 64 * WM_ * WN_, NPROD = NPROD_;
   static constexpr bool APRE = APRE_, BPRE = BPRE_;
-  static constexpr int TM = BM_ / 64, TN = BN_ / 64;
-  static constexpr int NA = APRE_ ? BM_ / 64 : BM_ / 32;    // f32: 8 lanes x 16 B per row, 32 rows per pass
-  static constexpr int NB = BPRE_ ? BN_ / 64 : BN_ / 32;    // pre-split: 4 lanes x 16 B (8 bf16) per row, 64 rows per pass
+  static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;
+  static constexpr int RPP_F32 = NT / 8, RPP_PRE = NT / 4;   // rows staged per pass: f32 8 lanes/row, planes 4 lanes/row
+  static constexpr int NA = APRE_ ? BM_ / RPP_PRE : BM_ / RPP_F32;
+  static constexpr int NB = BPRE_ ? BN_ / RPP_PRE : BN_ / RPP_F32;
   static constexpr int A_PL = BM_ * SP_ROW_BYTES, B_PL = BN_ * SP_ROW_BYTES;   // bytes per plane
   static constexpr int BUF = 3 * (A_PL + B_PL);
   static constexpr int LDS_BYTES = 2 * BUF;
@@ -61,18 +62,18 @@ __device__ __forceinline__ void split_mainloop(unsigned char* lds, int steps, LA
   constexpr int A_PL = Cfg::A_PL, B_PL = Cfg::B_PL, BUF = Cfg::BUF;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN, l31 = lane & 31, hh = lane >> 5;
 
   auto stage_a = [&](unsigned char* buf, int i) {       // (split +) store row i of A, then reload it
     if constexpr (Cfg::APRE) {
-      const int o = ((t >> 2) + 64 * i) * SP_ROW_BYTES + (t & 3) * 16;
+      const int o = ((t >> 2) + Cfg::RPP_PRE * i) * SP_ROW_BYTES + (t & 3) * 16;
 #pragma unroll
       for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(buf + p * A_PL + o) = la.value(i, p);
 #pragma unroll
       for (int p = 0; p < 3; ++p) la.issue(i, p);
     } else {
       const Split3 s = split3(la.value(i, 0));
-      const int o = ((t >> 3) + 32 * i) * SP_ROW_BYTES + (t & 7) * 8;
+      const int o = ((t >> 3) + Cfg::RPP_F32 * i) * SP_ROW_BYTES + (t & 7) * 8;
       *reinterpret_cast<bf16x4*>(buf + o) = s.h;
       *reinterpret_cast<bf16x4*>(buf + A_PL + o) = s.m;
       *reinterpret_cast<bf16x4*>(buf + 2 * A_PL + o) = s.l;
@@ -82,14 +83,14 @@ __device__ __forceinline__ void split_mainloop(unsigned char* lds, int steps, LA
   auto stage_b = [&](unsigned char* buf, int i) {
     unsigned char* b = buf + 3 * A_PL;
     if constexpr (Cfg::BPRE) {
-      const int o = ((t >> 2) + 64 * i) * SP_ROW_BYTES + (t & 3) * 16;
+      const int o = ((t >> 2) + Cfg::RPP_PRE * i) * SP_ROW_BYTES + (t & 3) * 16;
 #pragma unroll
       for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(b + p * B_PL + o) = lb.value(i, p);
 #pragma unroll
       for (int p = 0; p < 3; ++p) lb.issue(i, p);
     } else {
       const Split3 s = split3(lb.value(i, 0));
-      const int o = ((t >> 3) + 32 * i) * SP_ROW_BYTES + (t & 7) * 8;
+      const int o = ((t >> 3) + Cfg::RPP_F32 * i) * SP_ROW_BYTES + (t & 7) * 8;
       *reinterpret_cast<bf16x4*>(b + o) = s.h;
       *reinterpret_cast<bf16x4*>(b + B_PL + o) = s.m;
       *reinterpret_cast<bf16x4*>(b + 2 * B_PL + o) = s.l;
@@ -126,8 +127,8 @@ __device__ __forceinline__ void split_mainloop(unsigned char* lds, int steps, LA
   la.advance(); lb.advance();
   __syncthreads();
 
-  const int aoff = (wm * (Cfg::BM / 2) + l31) * SP_ROW_BYTES + 16 * hh;
-  const int boff = 3 * A_PL + (wn * (Cfg::BN / 2) + l31) * SP_ROW_BYTES + 16 * hh;
+  const int aoff = (wm * (Cfg::BM / Cfg::WM) + l31) * SP_ROW_BYTES + 16 * hh;
+  const int boff = 3 * A_PL + (wn * (Cfg::BN / Cfg::WN) + l31) * SP_ROW_BYTES + 16 * hh;
   bf16x8 fa[2][3][TM], fb[2][3][TN];
   auto read_frags = [&](const unsigned char* buf, int c, int slot) {
 #pragma unroll
@@ -180,7 +181,7 @@ __device__ __forceinline__ void split_mainloop(unsigned char* lds, int steps, LA
 }
 
 // Pre-split plane loader for a row-major operand: planes[p] + row*ld + k (bf16), rows >= nrows are zeros.
-template <int NR>
+template <int NR, int RPP = 64>
 struct PlaneRowLoader {
   const __bf16* p[3];
   size_t base[NR];
@@ -192,7 +193,7 @@ struct PlaneRowLoader {
     p[0] = planes; p[1] = planes + plane_stride; p[2] = planes + 2 * plane_stride;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int row = row0 + (threadIdx.x >> 2) + 64 * i;
+      const int row = row0 + (threadIdx.x >> 2) + RPP * i;
       ok |= (unsigned)(row < nrows) << i;
       base[i] = (size_t)min(row, nrows - 1) * ld + (threadIdx.x & 3) * 8;
     }

@@ -1,124 +1,127 @@
-"""Image I/O, resize, logger, Timer, device selection -- mirrors the reference's nn/utils.py:9-114
-on torch HIP tensors.  JPEG decode/encode use PIL (libjpeg ISLOW + fancy upsampling is PIL's
-default, the same algorithm as tf.image.decode_jpeg(dct_method='INTEGER_ACCURATE'))."""
+"""Host-side helpers with the reference's names (nn/utils.py:9-114 there): logger, long-side resize,
+JPEG load/store through PIL, device selection, a wall-clock Timer.  Tensors are torch HIP tensors;
+the only arithmetic here (resize) runs on the bilinear HIP kernel.
+
+JPEG notes: PIL decodes with libjpeg's ISLOW DCT + fancy upsampling, the algorithm
+tf.image.decode_jpeg(dct_method='INTEGER_ACCURATE') names; the writer always emits a JPEG at
+quality 100 with 4:2:0 chroma whatever the file extension says, as the reference's
+tf.image.encode_jpeg call does (utils.py:68 there)."""
 import logging
 import os
 import sys
 import time
-from typing import Optional
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
 
 from . import _ops
 
+_LOG_FORMAT = '%(asctime)s [%(levelname)s] %(name)s: %(message)s'
 logger = logging.getLogger(__name__)
 
 
 def make_logger(name: str):
+    """Install a stdout handler on logger `name` and make it the module-level `logger`."""
     global logger
-    logger = logging.getLogger(name)
-    if not logger.handlers:
-        sh = logging.StreamHandler(sys.stdout)
-        sh.setFormatter(
-            logging.Formatter('%(asctime)s [%(levelname)s] %(name)s: %(message)s', "%Y-%m-%d %H:%M:%S"))
-        logger.addHandler(sh)
-    logger.setLevel(logging.INFO)
+    log = logging.getLogger(name)
+    if not any(isinstance(h, logging.StreamHandler) for h in log.handlers):
+        handler = logging.StreamHandler(sys.stdout)
+        handler.setFormatter(logging.Formatter(_LOG_FORMAT, "%Y-%m-%d %H:%M:%S"))
+        log.addHandler(handler)
+    log.setLevel(logging.INFO)
+    logger = log
 
 
 def device() -> torch.device:
-    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
-def _validate_and_get_shape(base: torch.Tensor):
-    if base.dim() == 3:
-        h, w, _ = base.shape
-    elif base.dim() == 4:
-        _, h, w, _ = base.shape
-    else:
-        raise ValueError(f"Invalid rank: {base.dim()}")
-    return int(h), int(w)
+def _hw(t: torch.Tensor) -> Tuple[int, int]:
+    """(H, W) of an HWC or 1HWC tensor; anything else is an error, as in the reference."""
+    if t.dim() not in (3, 4):
+        raise ValueError(f"Invalid rank: {t.dim()}")
+    return int(t.shape[-3]), int(t.shape[-2])
+
+
+_validate_and_get_shape = _hw      # the reference's private name
 
 
 def resize(image: torch.Tensor, max_size: Optional[int]) -> torch.Tensor:
-    """reference nn/utils.py:32-37: long side -> max_size, sizes by Python doubles + int()."""
+    """Scale so the LONG side becomes `max_size` (up or down).  The target size is computed exactly like
+    the reference does -- Python doubles, then int() truncation: 321x481 at 64 -> 42x64."""
     if max_size is None:
         return image
-    h, w = _validate_and_get_shape(image)
+    h, w = _hw(image)
     factor = max(h / max_size, w / max_size)
     return _ops.resize_bilinear(image.float().contiguous(), int(h / factor), int(w / factor))
 
 
 def resize_like(image: torch.Tensor, base: torch.Tensor) -> torch.Tensor:
-    h, w = _validate_and_get_shape(base)
-    return _ops.resize_bilinear(image.float().contiguous(), h, w)
+    return _ops.resize_bilinear(image.float().contiguous(), *_hw(base))
 
 
 def load_image(path: str, max_size: Optional[int] = None, dtype: torch.dtype = torch.float32,
                batch_expand: bool = True) -> torch.Tensor:
-    """reference nn/utils.py:44-57.  uint8 stays uint8 unless `max_size` forces a (float) resize."""
+    """RGB image -> (1,H,W,3) float in [0,1] (or uint8 when asked; a resize makes it float, as in TF)."""
     if not os.path.exists(path):
         raise FileNotFoundError(f"File not found: {path}")
     from PIL import Image
-    arr = np.asarray(Image.open(path).convert("RGB"))
-    img = torch.from_numpy(arr.copy()).to(device())
+    with Image.open(path) as im:
+        pixels = np.array(im.convert("RGB"))
+    img = torch.from_numpy(pixels).to(device())
     if dtype.is_floating_point:
-        img = img.to(dtype) * (1.0 / 255.0)          # tf.image.convert_image_dtype(uint8 -> float)
+        img = img.to(dtype) * (1.0 / 255.0)
     img = resize(img, max_size)
-    if batch_expand:
-        return img[None]
-    return img
+    return img[None] if batch_expand else img
 
 
 def write_image(image: torch.Tensor, path: str):
-    """reference nn/utils.py:60-70: ALWAYS a JPEG (quality 100, 4:2:0), whatever the extension."""
-    rank = image.dim()
-    assert rank in [3, 4], f"Invalid rank: {rank}"
-    if rank == 4:
+    if image.dim() == 4:
         if image.shape[0] != 1:
             raise ValueError(f"Batch size must be 1. Got {image.shape[0]}")
         image = image[0]
+    assert image.dim() == 3, f"Invalid rank: {image.dim()}"
     from PIL import Image
-    arr = image.detach().to("cpu").numpy().astype(np.uint8)
-    Image.fromarray(arr, "RGB").save(path, format="JPEG", quality=100, subsampling=2)
+    Image.fromarray(image.detach().cpu().numpy().astype(np.uint8), "RGB").save(
+        path, format="JPEG", quality=100, subsampling=2)
     logger.info(f"Wrote image to {path}")
 
 
 def set_gpu(index: int = 0):
-    """reference nn/utils.py:73-85 (one visible device); here: torch.cuda.set_device."""
-    n = torch.cuda.device_count()
-    if n:
-        if index >= n:
-            raise ValueError(f"Invalid GPU ID: {index}")
-        torch.cuda.set_device(index)
-        logger.debug(f"Set GPU to {index}")
-    else:
+    """Select ONE device (the reference hides the others from TF; here: torch.cuda.set_device)."""
+    count = torch.cuda.device_count()
+    if count == 0:
         logger.info("GPU not found.")
+        return
+    if index >= count:
+        raise ValueError(f"Invalid GPU ID: {index}")
+    torch.cuda.set_device(index)
+    logger.debug(f"Set GPU to {index}")
 
 
-def is_jupyter_env():
-    if 'get_ipython' in globals():
-        shell = get_ipython().__class__.__name__  # type: ignore  # noqa: F821
-        if shell in ('ZMQInteractiveShell', 'Shell'):
-            return True
-    return False
+def is_jupyter_env() -> bool:
+    shell = globals().get('get_ipython')
+    return bool(shell) and shell().__class__.__name__ in ('ZMQInteractiveShell', 'Shell')
 
 
 class Timer:
+    """start() / stop() / elapsed_time (seconds, rounded to ms) -- the scope `run()` reports as 'Done in'."""
+
     def __init__(self):
-        self._start = 0.
-        self._stop = 0.
-        self._elapsed = 0.
+        self._t0: Optional[float] = None
+        self._elapsed = 0.0
 
     def start(self):
-        self._start = time.time()
+        self._t0 = time.time()
 
     def stop(self):
-        self._stop = time.time()
-        self._elapsed = round(self._stop - self._start, 3)
-        self._start = 0.
-        self._stop = 0.
+        if self._t0 is not None:
+            self._elapsed = round(time.time() - self._t0, 3)
+        self._t0 = None
 
     @property
-    def elapsed_time(self):
+    def elapsed_time(self) -> float:
         return self._elapsed

@@ -253,11 +253,12 @@ def main():
         conv_launches = sum(fam[n]["launches_per_step"] for n in conv_names)
         c3 = 2.0 * 9 * 3 * 64 * S * S
         algo = 2.0 * (conv_flops(params, S, S) - c3)       # direct-form FLOP of the 12 MFMA conv layers, fwd + dgrad
-        executed = 2.0 * sum(2.0 * (4 if "u_fwd" in L else 9) * L["cin"] * L["cout"] * a.shape[1] * a.shape[2]
-                             for L, a in zip(params.layers, eng.trunk.acts) if L["cin"] != 3)
+        macs_per_out = {0: 9.0, 2: 4.0, 4: 2.25}          # direct, F(2x2,3x3), F(4x4,3x3)
+        executed = 2.0 * sum(2.0 * macs_per_out[t] * L["cin"] * L["cout"] * a.shape[1] * a.shape[2]
+                             for L, a, t in zip(params.layers, eng.trunk.acts, eng.trunk.wtile) if L["cin"] != 3)
         tf = algo / (conv_ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA: conv3x3_mfma_pipe_kernel (direct implicit GEMM, Cin=64 "
-                                     "layers) + gemm_kc_pipe_kernel (16 Winograd F(2x2,3x3) GEMMs, Cin>=128 layers) "
+                                     "layers) + gemm_kc_pipe_kernel (batched Winograd GEMMs: F(4x4,3x3) from 32x32 px up, else F(2x2,3x3); Cin>=128 layers) "
                                      "incl. winograd_in/out_kernel; fwd + dgrad, all launches of a step",
                            "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,

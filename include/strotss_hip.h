@@ -80,16 +80,18 @@ int strotss_conv3x3_dgrad(const float* gout, int h, int w, int cout, const float
  *   std3: HOST pointer, 3 floats. */
 int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const float* w_tic,
                              const float* std3, float* gimg, int accumulate, void* stream);
-/* Winograd F(2x2,3x3) form of the two generic-layer entry points above (same results up to fp32
- * rounding of the transforms; 2.25x fewer MFMA MACs; used for the deep layers).  u_pok: (16, cout, cin)
- * = (G g G^T)[p] of the forward kernel, u_pik: (16, cin, cout) of the spatially flipped kernel; both
- * pre-computed once from the frozen weights.  workspace >= strotss_conv3x3_winograd_workspace_bytes(). */
-size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout);
+/* Winograd form of the two generic-layer entry points above (same results up to fp32 rounding of the
+ * transforms).  tile_m = 2: F(2x2,3x3), P = 16 transform-domain GEMMs, 2.25x fewer MACs than direct;
+ * tile_m = 4: F(4x4,3x3), P = 36 GEMMs, 4x fewer MACs (f32 error ~1e-5 of the output range instead of ~5e-7).
+ * u_pok: (P, cout, cin) = (G g G^T)[p] of the forward kernel, u_pik: (P, cin, cout) of the spatially flipped
+ * kernel; both pre-computed once from the frozen weights.
+ * workspace >= strotss_conv3x3_winograd_workspace_bytes(h, w, cin, cout, tile_m). */
+size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m);
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok,
-                                 const float* bias, int cout, float* out, void* workspace,
+                                 const float* bias, int cout, int tile_m, float* out, void* workspace,
                                  size_t workspace_bytes, void* stream);
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik, int cin,
-                                   const float* act_in, float* gin, void* workspace,
+                                   int tile_m, const float* act_in, float* gin, void* workspace,
                                    size_t workspace_bytes, void* stream);
 /* 2x2/2 VALID max-pool: out(h/2, w/2, c). */
 int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, void* stream);

@@ -130,6 +130,132 @@ __global__ __launch_bounds__(256) void winograd_out_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------- F(4x4, 3x3)
+// 36 transform-domain GEMMs per layer, 2.25 MACs per output (F(2x2,3x3): 4, direct: 9), V / M are 2.25x the
+// activation size (F(2x2,3x3): 4x).  Matrices of Lavin & Gray with points (0, +-1, +-2, inf); in f32 the
+// conv error grows to ~1e-5 of the output range (F(2x2,3x3): ~5e-7, direct: ~2e-7), see DESIGN.md.
+__device__ __forceinline__ void bt6(f32x4 (&d)[6]) {       // in-place B^T d
+  const f32x4 d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
+  d[0] = 4.f * d0 - 5.f * d2 + d4;
+  d[1] = -4.f * d1 - 4.f * d2 + d3 + d4;
+  d[2] = 4.f * d1 - 4.f * d2 - d3 + d4;
+  d[3] = -2.f * d1 - d2 + 2.f * d3 + d4;
+  d[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
+  d[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+// V: (36, T, C), T = ceil(H/4)*ceil(W/4); tile (ty,tx) reads input rows 4ty-1..4ty+4, cols 4tx-1..4tx+4
+__global__ __launch_bounds__(256) void winograd43_in_kernel(const float* __restrict__ in, int H, int W, int C4,
+                                                            int TH, int TW, float* __restrict__ V) {
+  const size_t T = (size_t)TH * TW;
+  const size_t total = T * C4;
+  const f32x4* src = reinterpret_cast<const f32x4*>(in);
+  f32x4* dst = reinterpret_cast<f32x4*>(V);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C4);
+    const size_t tile = e / C4;
+    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+    f32x4 d[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int y = 4 * ty - 1 + r;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int x = 4 * tx - 1 + q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && x >= 0 && x < W) v = src[((size_t)y * W + x) * C4 + c];
+        d[r][q] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {        // columns: t = B^T d
+      f32x4 col[6] = {d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]};
+      bt6(col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) d[r][q] = col[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {        // rows: V = t B
+      bt6(d[r]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dst[((size_t)(r * 6 + q) * T + tile) * C4 + c] = d[r][q];
+    }
+  }
+}
+
+// Y = A^T M A (4x4 outputs per tile);  out = relu(Y + bias)  or  (mask > 0 ? Y : 0)
+__global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __restrict__ Mw, int H, int W, int C4,
+                                                             int TH, int TW, const float* __restrict__ bias,
+                                                             const float* __restrict__ mask, int relu,
+                                                             float* __restrict__ out) {
+  const size_t T = (size_t)TH * TW;
+  const size_t total = T * C4;
+  const f32x4* src = reinterpret_cast<const f32x4*>(Mw);
+  const f32x4* msk = reinterpret_cast<const f32x4*>(mask);
+  f32x4* dst = reinterpret_cast<f32x4*>(out);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C4);
+    const size_t tile = e / C4;
+    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+    f32x4 s[4][6];                       // s = A^T M   (rows of A^T applied down the columns of M)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      f32x4 m[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) m[r] = src[((size_t)(r * 6 + q) * T + tile) * C4 + c];
+      s[0][q] = m[0] + m[1] + m[2] + m[3] + m[4];
+      s[1][q] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+      s[2][q] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+      s[3][q] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+    }
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b = reinterpret_cast<const f32x4*>(bias)[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = 4 * ty + r;
+      if (y >= H) continue;
+      f32x4 yv[4];
+      yv[0] = s[r][0] + s[r][1] + s[r][2] + s[r][3] + s[r][4] + b;
+      yv[1] = s[r][1] - s[r][2] + 2.f * s[r][3] - 2.f * s[r][4] + b;
+      yv[2] = s[r][1] + s[r][2] + 4.f * s[r][3] + 4.f * s[r][4] + b;
+      yv[3] = s[r][1] - s[r][2] + 8.f * s[r][3] - 8.f * s[r][4] + s[r][5] + b;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int x = 4 * tx + q;
+        if (x >= W) continue;
+        f32x4 v = yv[q];
+        const size_t o = ((size_t)y * W + x) * C4 + c;
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (mask) {
+          const f32x4 k = msk[o];
+          v[0] = k[0] > 0.f ? v[0] : 0.f; v[1] = k[1] > 0.f ? v[1] : 0.f;
+          v[2] = k[2] > 0.f ? v[2] : 0.f; v[3] = k[3] > 0.f ? v[3] : 0.f;
+        }
+        dst[o] = v;
+      }
+    }
+  }
+}
+
+static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
+                          const float* mask, int relu, float* out, void* workspace, size_t workspace_bytes,
+                          hipStream_t st) {
+  const int TH = (h + 3) / 4, TW = (w + 3) / 4;
+  const size_t T = (size_t)TH * TW;
+  Workspace ws(workspace, workspace_bytes);
+  float* V = ws.take<float>(36 * T * cin);
+  float* Mw = ws.take<float>(36 * T * cout);
+  if (!ws.ok()) return STROTSS_EINVAL;
+  const size_t tin = T * (cin / 4), tout = T * (cout / 4);
+  hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
+                     h, w, cin / 4, TH, TW, V);
+  const int rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
+                                    (long long)T * cout, (int)T, cout, cin, 36, st);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(winograd43_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
+                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out);
+  ST_LAUNCH_RET();
+}
+
 // Optional tiling of the tile range into passes whose V and M (16*Tc*(cin+cout) floats) would stay in the
 // 256 MiB Infinity Cache (STROTSS_WINO_CHUNK_MB > 0).  Measured on MI355X: every chunk size tried (48-160 MB)
 // is SLOWER than one pass (more, smaller launches; tails), so the default is 0 = one pass.
@@ -195,25 +321,38 @@ int winograd_run(const float* in, int h, int w, int cin, const float* U, const f
 
 extern "C" {
 
-size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout) {
+size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m) {
+  if (tile_m == 4) {
+    const size_t T4 = (size_t)((h + 3) / 4) * ((w + 3) / 4);
+    return ws_slice(36 * T4 * cin, sizeof(float)) + ws_slice(36 * T4 * cout, sizeof(float));
+  }
   const size_t T = (size_t)((h + 1) / 2) * ((w + 1) / 2);
   return ws_slice(16 * T * cin * 3 / 2 + 64, sizeof(float)) + ws_slice(16 * T * cout, sizeof(float)) +
          ws_slice((size_t)3 * 16 * cout * cin, sizeof(unsigned short));
 }
 
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok, const float* bias,
-                                 int cout, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                                 int cout, int tile_m, float* out, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   ST_CHECK_ARG(in && u_pok && bias && out && workspace && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
+  if (tile_m == 4)
+    return winograd43_run(in, h, w, cin, u_pok, bias, cout, nullptr, 1, out, workspace, workspace_bytes,
+                          (hipStream_t)stream);
   return winograd_run(in, h, w, cin, u_pok, bias, cout, nullptr, 1, out, workspace, workspace_bytes,
                       (hipStream_t)stream);
 }
 
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik, int cin,
-                                   const float* act_in, float* gin, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
+                                   int tile_m, const float* act_in, float* gin, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(gout && u_pik && gin && workspace && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
+  if (tile_m == 4)
+    return winograd43_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
+                          (hipStream_t)stream);
   return winograd_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
                       (hipStream_t)stream);
 }

@@ -96,18 +96,24 @@ def conv3x3_c3_dgrad(gout, w_tic, gimg=None, accumulate=False, std=None):
     return gimg
 
 
-def _wino_ws(h, w, cin, cout, device):
-    nb = _hip.lib().strotss_conv3x3_winograd_workspace_bytes(h, w, cin, cout)
+def _wino_ws(h, w, cin, cout, tile_m, device):
+    nb = _hip.lib().strotss_conv3x3_winograd_workspace_bytes(h, w, cin, cout, tile_m)
     return workspaces.get("winograd", nb, device), nb
 
 
+def _tile_m(u: torch.Tensor) -> int:
+    return {16: 2, 36: 4}[int(u.shape[0])]
+
+
 def conv3x3_winograd_fwd(x, u_pok, bias, out=None):
+    """u_pok: (16, cout, cin) -> F(2x2,3x3), (36, cout, cin) -> F(4x4,3x3)."""
     require(x, "conv input"); h, w, cin = hwc(x)
     cout = bias.numel()
     if out is None:
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
-    ws, nb = _wino_ws(h, w, cin, cout, x.device)
-    check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(bias), cout, ptr(out),
+    m = _tile_m(u_pok)
+    ws, nb = _wino_ws(h, w, cin, cout, m, x.device)
+    check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(bias), cout, m, ptr(out),
                                                   ptr(ws), nb, stream_ptr()), "conv3x3_winograd_fwd")
     return out
 
@@ -116,19 +122,24 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
     require(gout, "conv grad"); h, w, cout = hwc(gout)
     if out is None:
         out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
-    ws, nb = _wino_ws(h, w, cout, cin, gout.device)
-    check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), cin, ptr(act_in), ptr(out),
+    m = _tile_m(u_pik)
+    ws, nb = _wino_ws(h, w, cout, cin, m, gout.device)
+    check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), cin, m, ptr(act_in), ptr(out),
                                                     ptr(ws), nb, stream_ptr()), "conv3x3_winograd_dgrad")
     return out
 
 
-def winograd_weights(g: torch.Tensor) -> torch.Tensor:
-    """g: (N, K, 3, 3) kernel as [out-channel][in-channel][r][q] (float64 on the host) ->
-    U (16, N, K) float32 with U[4*xi+nu] = (G g G^T)[xi, nu]."""
-    G = torch.tensor([[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]], dtype=torch.float64,
-                     device=g.device)
+_WINO_G = {2: [[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]],
+           4: [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+               [1 / 24, -1 / 12, 1 / 6], [0, 0, 1.0]]}
+
+
+def winograd_weights(g: torch.Tensor, tile_m: int = 2) -> torch.Tensor:
+    """g: (N, K, 3, 3) kernel as [out-channel][in-channel][r][q] -> U (P, N, K) float32 with
+    U[a*(m+2)+b] = (G g G^T)[a, b], computed in float64 (P = 16 for tile_m = 2, 36 for tile_m = 4)."""
+    G = torch.tensor(_WINO_G[tile_m], dtype=torch.float64, device=g.device)
     u = torch.einsum("ar,nkrq,bq->abnk", G, g.double(), G)
-    return u.reshape(16, g.shape[0], g.shape[1]).float().contiguous()
+    return u.reshape(G.shape[0] ** 2, g.shape[0], g.shape[1]).float().contiguous()
 
 
 def maxpool2_fwd(x, out=None):

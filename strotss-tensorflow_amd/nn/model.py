@@ -83,6 +83,18 @@ def use_winograd(cin: int, cout: int) -> bool:
     return cin >= 128 and cin % 32 == 0 and cout % 64 == 0      # measured per layer: tools/conv_bench.py
 
 
+def winograd_tile(h: int, w: int) -> int:
+    """Output tile of a Winograd layer at spatial size (h, w).  F(4x4,3x3) does 2.25 MACs per output (F(2x2,3x3):
+    4) and its transform-domain tensors are 2.25x the activations (4x), at ~16x the f32 rounding error of the
+    convolution (~1e-5 of the output range instead of ~5e-7; every step-level parity test holds at unchanged
+    tolerances).  Measured on MI355X it wins from 32x32 pixels up; below that the 2x2 tiling fills the GEMM
+    tiles better.  STROTSS_WINOGRAD_TILE=2 | 4 forces one of them."""
+    mode = os.environ.get("STROTSS_WINOGRAD_TILE", "auto")
+    if mode in ("2", "4"):
+        return int(mode)
+    return 4 if h * w >= 1024 else 2
+
+
 class VGGParams:
     """Frozen weights on the device in the layouts the kernels want (built once)."""
 
@@ -133,8 +145,9 @@ class VGGParams:
                 L["w_bwd"] = w.flip(0, 1).reshape(9, cin, cout).contiguous().to(device)           # (9,cin,cout)
                 if use_winograd(cin, cout):
                     # forward: g[co][ci][r][q] = W[r,q,ci,co]; dgrad: g'[ci][co][r][q] = W[2-r,2-q,ci,co]
-                    L["u_fwd"] = _ops.winograd_weights(w.permute(3, 2, 0, 1)).to(device)
-                    L["u_bwd"] = _ops.winograd_weights(w.flip(0, 1).permute(2, 3, 0, 1)).to(device)
+                    L["u_fwd"] = {m: _ops.winograd_weights(w.permute(3, 2, 0, 1), m).to(device) for m in (2, 4)}
+                    L["u_bwd"] = {m: _ops.winograd_weights(w.flip(0, 1).permute(2, 3, 0, 1), m).to(device)
+                                  for m in (2, 4)}
             self.layers.append(L)
         self.device = device
 
@@ -179,6 +192,9 @@ class VGGTrunk:
                 li += 1
         self.taps = params.tap_layer_indices
         self.with_grad = with_grad
+        # Winograd tile per layer for this image size
+        self.wtile = [winograd_tile(int(a.shape[1]), int(a.shape[2])) if "u_fwd" in L else 0
+                      for L, a in zip(params.layers, self.acts)]
         if with_grad:
             self.grads = [torch.empty_like(a) for a in self.acts]
             self.gpools = [torch.empty_like(p) for p in self.pools]
@@ -202,7 +218,7 @@ class VGGTrunk:
                 if L["cin"] == 3:
                     _ops.conv3x3_c3_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li], mean=P.mean, std=P.std)
                 elif "u_fwd" in L:
-                    _ops.conv3x3_winograd_fwd(x, L["u_fwd"], L["bias"], out=self.acts[li])
+                    _ops.conv3x3_winograd_fwd(x, L["u_fwd"][self.wtile[li]], L["bias"], out=self.acts[li])
                 else:
                     _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
         return [self.acts[i] for i in self.taps]
@@ -230,16 +246,16 @@ class VGGTrunk:
                 if kind == 'img':
                     _ops.conv3x3_c3_dgrad(self.grads[li], L["w_bwd"], self.gimg, accumulate=False, std=P.std)
                     scatter(-1)
-                elif kind == 'conv':
-                    dgrad = _ops.conv3x3_winograd_dgrad if "u_bwd" in L else _ops.conv3x3_dgrad
-                    dgrad(self.grads[li], L["u_bwd"] if "u_bwd" in L else L["w_bwd"], L["cin"], act_in=self.acts[si],
-                          out=self.grads[si])
-                    if si in tapped:
-                        scatter(si)
                 else:
-                    dgrad = _ops.conv3x3_winograd_dgrad if "u_bwd" in L else _ops.conv3x3_dgrad
-                    dgrad(self.grads[li], L["u_bwd"] if "u_bwd" in L else L["w_bwd"], L["cin"], act_in=None,
-                          out=self.gpools[si])
+                    wino = "u_bwd" in L
+                    dgrad = _ops.conv3x3_winograd_dgrad if wino else _ops.conv3x3_dgrad
+                    wts = L["u_bwd"][self.wtile[li]] if wino else L["w_bwd"]
+                    if kind == 'conv':
+                        dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si])
+                        if si in tapped:
+                            scatter(si)
+                    else:
+                        dgrad(self.grads[li], wts, L["cin"], act_in=None, out=self.gpools[si])
         return self.gimg
 
 

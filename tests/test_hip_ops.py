@@ -128,27 +128,30 @@ def test_conv_generic_fwd_and_dgrad(ops, cfg):
 
 @pytest.mark.parametrize("cfg", [(16, 24, 128, 256), (9, 7, 256, 256), (5, 3, 512, 512), (33, 20, 64, 64),
                                  (1, 1, 128, 128), (2, 4, 256, 512)])
-def test_conv_winograd_fwd_and_dgrad(ops, cfg):
-    """Winograd F(2x2,3x3) entry points == the direct convolution (odd sizes exercise partial tiles)."""
+@pytest.mark.parametrize("tile_m", [2, 4])
+def test_conv_winograd_fwd_and_dgrad(ops, cfg, tile_m):
+    """Winograd F(2x2,3x3) / F(4x4,3x3) entry points == the direct convolution (odd sizes exercise partial
+    tiles).  Tolerances (relative to the output range): 1e-5 for F(2x2,3x3), 5e-5 for F(4x4,3x3)."""
     h, w, cin, cout = cfg
+    tol = 1e-5 if tile_m == 2 else 5e-5
     g = torch.Generator().manual_seed(h * w + cin + 1)
     x = torch.relu(torch.randn(1, h, w, cin, generator=g, dtype=torch.float64))
     wt = torch.randn(3, 3, cin, cout, generator=g, dtype=torch.float64) * (2.0 / (9 * cin)) ** 0.5
     b = torch.randn(cout, generator=g, dtype=torch.float64) * 0.1
     xin = x.clone().requires_grad_(True)
     y = _conv_ref(xin, wt, b)
-    u_f = ops.winograd_weights(wt.permute(3, 2, 0, 1)).cuda()
+    u_f = ops.winograd_weights(wt.permute(3, 2, 0, 1), tile_m).cuda()
     got = ops.conv3x3_winograd_fwd(dev(x), u_f, dev(b)).cpu().numpy()
-    assert rel_err(got, y.detach().numpy()) < 1e-5
+    assert rel_err(got, y.detach().numpy()) < tol
     gy = torch.randn(1, h, w, cout, generator=g, dtype=torch.float64)
     ypre = _conv_ref(xin, wt, b, relu=False)
     (ypre * gy).sum().backward()
-    u_b = ops.winograd_weights(wt.flip(0, 1).permute(2, 3, 0, 1)).cuda()
+    u_b = ops.winograd_weights(wt.flip(0, 1).permute(2, 3, 0, 1), tile_m).cuda()
     if cin % 64 == 0:
         got = ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin).cpu().numpy()
-        assert rel_err(got, xin.grad.numpy()) < 1e-5
+        assert rel_err(got, xin.grad.numpy()) < tol
         got = ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin, act_in=dev(x)).cpu().numpy()
-        assert rel_err(got, (xin.grad * (x > 0)).numpy()) < 1e-5
+        assert rel_err(got, (xin.grad * (x > 0)).numpy()) < tol
 
 
 def test_split_gemm_accuracy():

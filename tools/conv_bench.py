@@ -32,8 +32,9 @@ def main():
         out = torch.empty(1, hw, hw, cout, device=dev)
         gin = torch.empty(1, hw, hw, cin, device=dev)
         flops = 2.0 * 9 * cin * cout * hw * hw
-        u = (torch.randn(16, cout, cin, generator=g) * 0.05).to(dev)
-        ub = (torch.randn(16, cin, cout, generator=g) * 0.05).to(dev)
+        P = 36 if os.environ.get("STROTSS_WINOGRAD_TILE", "2") == "4" else 16
+        u = (torch.randn(P, cout, cin, generator=g) * 0.05).to(dev)
+        ub = (torch.randn(P, cin, cout, generator=g) * 0.05).to(dev)
         for kind in ("fwd", "dgrad", "wfwd", "wdgrad"):
             if kind.endswith("dgrad") and cin % 64:
                 continue

@@ -367,6 +367,114 @@ __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_kernel(const float* __re
   }
 }
 
+// ---- first layer on the MFMA (cout == 64): one wave = 32 pixels x 64 channels, K = 27 (+1 zero) as 14
+// v_mfma_f32_32x32x2_f32 per 32-channel half.  A (pixels x taps) is gathered straight from the 12-byte pixels
+// with the preprocess applied in flight; B (taps x channels) sits in LDS.  HBM-bound on its 256-byte rows.
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* __restrict__ img, int H, int W,
+                                                                  const float* __restrict__ w_kio,
+                                                                  const float* __restrict__ bias,
+                                                                  f32x4 mean_, f32x4 istd_, float* __restrict__ out) {
+  __shared__ float wsm[28 * 64];
+  for (int i = threadIdx.x; i < 28 * 64; i += 256) wsm[i] = (i < 27 * 64) ? w_kio[i] : 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int HW = H * W;
+  const int groups = (HW + 31) / 32;
+  const float mean[3] = {mean_[0], mean_[1], mean_[2]}, istd[3] = {istd_[0], istd_[1], istd_[2]};
+  const float b0 = bias[l31], b1 = bias[32 + l31];
+  for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
+    const int p = g * 32 + l31;
+    const bool live = p < HW;
+    const int y = live ? p / W : 0, x = live ? p - y * W : 0;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+#pragma unroll
+    for (int s2 = 0; s2 < 14; ++s2) {
+      // this lane's k = 2*s2 + hh  ->  (tap, channel); both candidates are compile-time, hh selects
+      const int k0 = 2 * s2, k1 = 2 * s2 + 1;
+      const int tap = hh ? k1 / 3 : k0 / 3, ch = hh ? k1 % 3 : k0 % 3;
+      float a = 0.f;
+      if (tap < 9) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (live && yy >= 0 && yy < H && xx >= 0 && xx < W)
+          a = (img[((size_t)yy * W + xx) * 3 + ch] - mean[ch]) * istd[ch];
+      }
+      const float w0 = wsm[(2 * s2 + hh) * 64 + l31], w1 = wsm[(2 * s2 + hh) * 64 + 32 + l31];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+      const int pp = g * 32 + row;
+      if (pp < HW) {
+        out[(size_t)pp * 64 + l31] = fmaxf(acc0[reg], 0.f);
+        out[(size_t)pp * 64 + 32 + l31] = fmaxf(acc1[reg], 0.f);
+      }
+    }
+  }
+}
+
+// ---- pixel gradient through an LDS halo tile (cout == 64): a block owns 4 x 32 pixels; the 6 x 34 x 64
+// patch of gout is staged once (each element is read 9 times from LDS instead of from L1/L2); 4 lanes per
+// pixel take 16 channels each, as in the generic kernel.
+#define C3D_TH 4
+#define C3D_TW 32
+#define C3D_PS 68      // padded pixel stride in floats (64 + 4): 16-lane b128 groups hit distinct banks
+__global__ __launch_bounds__(512) void conv3x3_c3_dgrad_lds_kernel(const float* __restrict__ gout, int H, int W,
+                                                                   const float* __restrict__ w_tic, f32x4 istd,
+                                                                   float* __restrict__ gimg, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float tile[(C3D_TH + 2) * (C3D_TW + 2) * C3D_PS];
+  __shared__ __attribute__((aligned(16))) float wsm[27 * 64];
+  const int t = threadIdx.x;
+  for (int i = t; i < 27 * 64; i += 512) wsm[i] = w_tic[i];
+  const int tiles_x = (W + C3D_TW - 1) / C3D_TW;
+  const int ty0 = (blockIdx.x / tiles_x) * C3D_TH, tx0 = (blockIdx.x % tiles_x) * C3D_TW;
+  // stage (TH+2) x (TW+2) pixels x 64 channels, zero outside the image
+  constexpr int NPIX = (C3D_TH + 2) * (C3D_TW + 2);
+  for (int e = t; e < NPIX * 16; e += 512) {
+    const int pix = e >> 4, c4 = e & 15;
+    const int py = pix / (C3D_TW + 2), px = pix - py * (C3D_TW + 2);
+    const int y = ty0 + py - 1, x = tx0 + px - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const f32x4*>(&gout[((size_t)y * W + x) * 64 + c4 * 4]);
+    *reinterpret_cast<f32x4*>(&tile[pix * C3D_PS + c4 * 4]) = v;
+  }
+  __syncthreads();
+  const int sub = t & 3, lp = t >> 2;            // 128 pixels x 4 channel quarters
+  const int ly = lp / C3D_TW, lx = lp - ly * C3D_TW;
+  const int y = ty0 + ly, x = tx0 + lx;
+  const int co0 = sub * 16;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const float* q = &tile[((ly + tap / 3) * (C3D_TW + 2) + lx + tap % 3) * C3D_PS + co0];
+    const float* w0 = &wsm[(tap * 3 + 0) * 64 + co0];
+    const float* w1 = &wsm[(tap * 3 + 1) * 64 + co0];
+    const float* w2 = &wsm[(tap * 3 + 2) * 64 + co0];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(q + 4 * g);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + 4 * g);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + 4 * g);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(w2 + 4 * g);
+      s0 += gv[0] * a[0] + gv[1] * a[1] + gv[2] * a[2] + gv[3] * a[3];
+      s1 += gv[0] * b[0] + gv[1] * b[1] + gv[2] * b[2] + gv[3] * b[3];
+      s2 += gv[0] * c[0] + gv[1] * c[1] + gv[2] * c[2] + gv[3] * c[3];
+    }
+  }
+  s0 += __shfl_xor(s0, 1, 64); s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+  s0 += __shfl_xor(s0, 2, 64); s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+  if (sub == 0 && y < H && x < W) {
+    float* g = gimg + ((size_t)y * W + x) * 3;
+    const float a0 = s0 * istd[0], a1 = s1 * istd[1], a2 = s2 * istd[2];
+    if (accumulate) { g[0] += a0; g[1] += a1; g[2] += a2; }
+    else { g[0] = a0; g[1] = a1; g[2] = a2; }
+  }
+}
+
 // ---------------------------------------------------------------- 2x2/2 VALID max-pool
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ in, int H, int W, int C4,
                                                            float* __restrict__ out) {
@@ -431,6 +539,12 @@ int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, c
   ST_CHECK_ARG(cout >= 16 && cout <= 256 && (cout & (cout - 1)) == 0, STROTSS_EALIGN);
   const f32x4 m = {mean3[0], mean3[1], mean3[2], 0.f};
   const f32x4 is = {1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2], 0.f};
+  if (cout == 64 && conv_variant() != 1) {
+    const int groups = cdiv((int64_t)h * w, 32);
+    hipLaunchKernelGGL(conv3x3_c3_fwd_mfma_kernel, dim3(min(4096, cdiv(groups, 4))), dim3(256), 0, (hipStream_t)stream,
+                       img, h, w, w_kio, bias, m, is, out);
+    ST_LAUNCH_RET();
+  }
   const int ppb = 256 / (cout >> 4);
   hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(cdiv((int64_t)h * w, ppb)), dim3(256),
                      27 * cout * sizeof(float), (hipStream_t)stream, img, h, w, w_kio, bias, cout, m, is, out);
@@ -457,6 +571,12 @@ int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const fl
   ST_CHECK_ARG(gout && w_tic && std3 && gimg && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cout >= 16 && cout <= 256 && (cout & (cout - 1)) == 0, STROTSS_EALIGN);
   const f32x4 is = {1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2], 0.f};
+  if (cout == 64 && conv_variant() != 1) {
+    const int nblk = cdiv(h, C3D_TH) * cdiv(w, C3D_TW);
+    hipLaunchKernelGGL(conv3x3_c3_dgrad_lds_kernel, dim3(nblk), dim3(512), 0, (hipStream_t)stream, gout, h, w, w_tic,
+                       is, gimg, accumulate);
+    ST_LAUNCH_RET();
+  }
   const int ppb = 256 / (cout >> 4);
   hipLaunchKernelGGL(conv3x3_c3_dgrad_kernel, dim3(cdiv((int64_t)h * w, ppb)), dim3(256),
                      27 * cout * sizeof(float), (hipStream_t)stream, gout, h, w, cout, w_tic, is, gimg,

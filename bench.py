@@ -257,9 +257,9 @@ def main():
         executed = 2.0 * sum(2.0 * macs_per_out[t] * L["cin"] * L["cout"] * a.shape[1] * a.shape[2]
                              for L, a, t in zip(params.layers, eng.trunk.acts, eng.trunk.wtile) if L["cin"] != 3)
         tf = algo / (conv_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA: conv3x3_mfma_pipe_kernel (direct implicit GEMM, Cin=64 "
-                                     "layers) + gemm_kc_pipe_kernel (batched Winograd GEMMs: F(4x4,3x3) from 32x32 px up, else F(2x2,3x3); Cin>=128 layers) "
-                                     "incl. winograd_in/out_kernel; fwd + dgrad, all launches of a step",
+        out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA: gemm_kc_pipe_kernel (batched Winograd-domain GEMMs: F(4x4,3x3) from "
+                                     "32x32 px up, F(2x2,3x3) below for Cin>=128) incl. winograd*_in/out_kernel, and "
+                                     "conv3x3_mfma_pipe_kernel (direct implicit GEMM, small Cin=64 layers); fwd + dgrad, all launches of a step",
                            "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                            "algorithmic_gflop_per_step": round(algo / 1e9, 1),

@@ -71,28 +71,27 @@ def load_weights(path: str, vgg_type: str = '16') -> List[Tuple[torch.Tensor, to
 
 
 def use_winograd(cin: int, cout: int) -> bool:
-    """Layers that run in Winograd F(2x2,3x3) form: Cin >= 128 (block2_conv2 and deeper), where the
-    f32 MFMA -- not HBM -- is the limit and the 4x larger transform-domain tensors are affordable
-    (measured on MI355X at 1024 px: 1.2x at 128->128 up to 2.0x at 512->512; a loss at Cin = 64).  STROTSS_WINOGRAD=0
-    disables it, =all forces it for every generic layer."""
-    mode = os.environ.get("STROTSS_WINOGRAD", "auto")
-    if mode == "0":
+    """Layers that MAY run in Winograd form (their transformed weights are prepared): every generic layer.
+    STROTSS_WINOGRAD=0 disables Winograd altogether (direct implicit GEMM everywhere)."""
+    if os.environ.get("STROTSS_WINOGRAD", "auto") == "0":
         return False
-    if mode == "all":
-        return cin % 32 == 0 and cout % 64 == 0
-    return cin >= 128 and cin % 32 == 0 and cout % 64 == 0      # measured per layer: tools/conv_bench.py
+    return cin % 32 == 0 and cout % 64 == 0
 
 
-def winograd_tile(h: int, w: int) -> int:
-    """Output tile of a Winograd layer at spatial size (h, w).  F(4x4,3x3) does 2.25 MACs per output (F(2x2,3x3):
-    4) and its transform-domain tensors are 2.25x the activations (4x), at ~16x the f32 rounding error of the
-    convolution (~1e-5 of the output range instead of ~5e-7; every step-level parity test holds at unchanged
-    tolerances).  Measured on MI355X it wins from 32x32 pixels up; below that the 2x2 tiling fills the GEMM
-    tiles better.  STROTSS_WINOGRAD_TILE=2 | 4 forces one of them."""
+def winograd_tile(h: int, w: int, cin: int = 128) -> int:
+    """0 = direct kernel, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for a layer with `cin` input channels at (h, w).
+    Measured on MI355X (tools/conv_bench.py): F(4x4,3x3) -- 2.25 MACs per output, transform tensors 2.25x the
+    activations -- wins from 32x32 pixels up for every channel count (1.2x at 64->64 ... 2.9x at 512->512 over
+    the direct kernel); below that F(2x2,3x3) (4 MACs, 4x tensors) wins for Cin >= 128 and the direct kernel
+    for Cin = 64.  f32 rounding of the convolution: direct ~2e-7, F(2x2,3x3) ~5e-7, F(4x4,3x3) ~1e-5 of the
+    output range; every step-level parity test holds at unchanged tolerances.
+    STROTSS_WINOGRAD_TILE=2 | 4 forces one tiling for the Cin >= 128 layers."""
     mode = os.environ.get("STROTSS_WINOGRAD_TILE", "auto")
     if mode in ("2", "4"):
-        return int(mode)
-    return 4 if h * w >= 1024 else 2
+        return int(mode) if cin >= 128 else 0
+    if h * w >= 1024:
+        return 4
+    return 2 if cin >= 128 else 0
 
 
 class VGGParams:
@@ -193,7 +192,7 @@ class VGGTrunk:
         self.taps = params.tap_layer_indices
         self.with_grad = with_grad
         # Winograd tile per layer for this image size
-        self.wtile = [winograd_tile(int(a.shape[1]), int(a.shape[2])) if "u_fwd" in L else 0
+        self.wtile = [winograd_tile(int(a.shape[1]), int(a.shape[2]), L["cin"]) if "u_fwd" in L else 0
                       for L, a in zip(params.layers, self.acts)]
         if with_grad:
             self.grads = [torch.empty_like(a) for a in self.acts]
@@ -217,7 +216,7 @@ class VGGTrunk:
                 x = self._src(src)
                 if L["cin"] == 3:
                     _ops.conv3x3_c3_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li], mean=P.mean, std=P.std)
-                elif "u_fwd" in L:
+                elif self.wtile[li]:
                     _ops.conv3x3_winograd_fwd(x, L["u_fwd"][self.wtile[li]], L["bias"], out=self.acts[li])
                 else:
                     _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
@@ -247,7 +246,7 @@ class VGGTrunk:
                     _ops.conv3x3_c3_dgrad(self.grads[li], L["w_bwd"], self.gimg, accumulate=False, std=P.std)
                     scatter(-1)
                 else:
-                    wino = "u_bwd" in L
+                    wino = self.wtile[li] != 0
                     dgrad = _ops.conv3x3_winograd_dgrad if wino else _ops.conv3x3_dgrad
                     wts = L["u_bwd"][self.wtile[li]] if wino else L["w_bwd"]
                     if kind == 'conv':

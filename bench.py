@@ -145,6 +145,52 @@ def pairwise_roofline(dev, iters=50):
             "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
 
 
+def pmc_traffic(path=os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.csv")):
+    """HBM bytes per conv launch from the committed PMC passes (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    in separate runs of this script, condensed by tools/summarize_rocprof.py with the gfx950 FETCH_SIZE x2
+    correction).  One conv launch = one C-ABI call = input transform + batched GEMM + output transform, so the
+    family's bytes are divided by its GEMM launches.  None when the summary is absent."""
+    import csv
+    if not os.path.exists(path):
+        return None
+    fam = ("winograd", "gemm_kc_pipe_kernel", "conv3x3_mfma_pipe_kernel")
+    total, launches = 0.0, 0
+    with open(path) as f:
+        rd = csv.reader(f)
+        next(rd)
+        for name, _grid, n, r_mb, w_mb in rd:
+            if not name.startswith(fam) or ("gemm_kc" in name and "EpiScaleStore" not in name):
+                continue
+            total += int(n) * (float(r_mb) + float(w_mb)) * 1e6
+            if not name.startswith("winograd"):
+                launches += int(n)
+    return total / launches if launches else None
+
+
+def wall_clock_to_output(dev, size=1024, level=5, max_iter=200):
+    """The reference's Timer scope (run_strotss.py:44-45,159): model build + image load + all scales + postprocess
+    + JPEG write, through the CLI's run() on a synthetic `size`-px pair written to a temporary directory."""
+    import tempfile
+    import run_strotss
+    from nn import utils
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = []
+        for name, seed in (("content.jpg", 100), ("style.jpg", 200)):
+            paths.append(os.path.join(tmp, name))
+            utils.write_image(synth_image(size, size, seed) * 255.0, paths[-1])
+        out_path = os.path.join(tmp, "out.jpg")
+        args = run_strotss.build_parser().parse_args(
+            [paths[0], paths[1], "-o", out_path, "--max_size", str(size), "--level", str(level), "--max_iter",
+             str(max_iter), "--log_every", str(max_iter)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_strotss.run(args)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"seconds": round(dt, 2), "config": f"{size}px synthetic pair, --level {level} --max_iter {max_iter} "
+            f"(scales 64..{64 << (level - 1)}), incl. VGG build, JPEG decode/encode, per-scale setup, hipGraph capture"}
+
+
 def cpu_baseline(scale, budget_s=25.0):
     """fp32 torch-CPU oracle (the restatement of the reference) on the same synthetic workload."""
     from oracle import strotss_oracle as O
@@ -195,6 +241,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-output run of the whole CLI schedule")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,7 +308,9 @@ def main():
                                      "32x32 px up, F(2x2,3x3) below for Cin>=128) incl. winograd*_in/out_kernel, and "
                                      "conv3x3_mfma_pipe_kernel (direct implicit GEMM, small Cin=64 layers); fwd + dgrad, all launches of a step",
                            "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                           "traffic_unit": "HBM bytes per conv launch, PMC FETCH_SIZE x2 + WRITE_SIZE "
+                                           "(profiles/r01_hbm_traffic_by_kernel.csv)",
                            "algorithmic_gflop_per_step": round(algo / 1e9, 1),
                            "mfma_executed_gflop_per_step": round(executed / 1e9, 1),
                            "mfma_executed_tflops": round(executed / (conv_ms * 1e-3) / 1e12, 2),
@@ -293,6 +342,8 @@ def main():
             total += 200.0 / out["value"]
             out["pyramid"] = {"steps_per_sec_by_scale": pyr,
                               "projected_optimisation_wall_clock_s_5x200": round(total, 2)}
+    if rank == 0 and not args.no_e2e and world == 1 and S == 1024:
+        out["wall_clock_to_output"] = wall_clock_to_output(dev)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(S)
     if rank == 0:

@@ -127,7 +127,7 @@ def test_conv_generic_fwd_and_dgrad(ops, cfg):
 
 
 @pytest.mark.parametrize("cfg", [(16, 24, 128, 256), (9, 7, 256, 256), (5, 3, 512, 512), (33, 20, 64, 64),
-                                 (1, 1, 128, 128), (2, 4, 256, 512)])
+                                 (1, 1, 128, 128), (2, 4, 256, 512), (70, 37, 128, 64), (16, 32, 64, 128), (19, 45, 32, 64)])
 @pytest.mark.parametrize("tile_m", [2, 4])
 def test_conv_winograd_fwd_and_dgrad(ops, cfg, tile_m):
     """Winograd F(2x2,3x3) / F(4x4,3x3) entry points == the direct convolution (odd sizes exercise partial

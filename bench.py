@@ -170,10 +170,13 @@ def pmc_traffic(path=os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.c
 def wall_clock_to_output(dev, size=1024, level=5, max_iter=200):
     """The reference's Timer scope (run_strotss.py:44-45,159): model build + image load + all scales + postprocess
     + JPEG write, through the CLI's run() on a synthetic `size`-px pair written to a temporary directory."""
+    import contextlib
+    import logging
     import tempfile
     import run_strotss
     from nn import utils
-    with tempfile.TemporaryDirectory() as tmp:
+    logging.getLogger('STROTSS').setLevel(logging.WARNING)       # stdout carries the JSON line only
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(sys.stderr):
         paths = []
         for name, seed in (("content.jpg", 100), ("style.jpg", 200)):
             paths.append(os.path.join(tmp, name))

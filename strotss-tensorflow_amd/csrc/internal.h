@@ -16,10 +16,10 @@ int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, cons
 int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                        float* C, int ldc, long long strideC, int M, int N, int K, int batch, hipStream_t s);
 
-// winograd_fused.hip: F(4x4,3x3) in one kernel for 64 output channels (cin % 16 == 0)
-bool st_winograd43_fused64_enabled();
-int st_winograd43_fused64(const float* in, int h, int w, int cin, const float* U, const float* bias,
-                          const float* mask, int relu, float* out, hipStream_t st);
+// winograd_fused.hip: F(4x4,3x3) in one kernel (cin % 16 == 0, cout % 32 == 0)
+bool st_winograd43_fused_enabled(int h, int w, int cout);
+int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
+                        const float* mask, int relu, float* out, hipStream_t st);
 
 int st_split_planes(const float* x, size_t n, void* planes, hipStream_t s);
 int st_gemm_nt_batched_split(const void* A, int a_pre, size_t a_plane_stride, int lda, long long strideA,

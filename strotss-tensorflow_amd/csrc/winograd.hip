@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                           const float* mask, int relu, float* out, void* workspace, size_t workspace_bytes,
                           hipStream_t st) {
-  if (cout == 64 && cin % 16 == 0 && st_winograd43_fused64_enabled())      // everything on chip, no workspace
-    return st_winograd43_fused64(in, h, w, cin, U, bias, mask, relu, out, st);
+  if (cin % 16 == 0 && st_winograd43_fused_enabled(h, w, cout))      // everything on chip, no workspace
+    return st_winograd43_fused(in, h, w, cin, U, bias, cout, mask, relu, out, st);
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const size_t T = (size_t)TH * TW;
   Workspace ws(workspace, workspace_bytes);

@@ -85,14 +85,21 @@ int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const fl
  * tile_m = 4: F(4x4,3x3), P = 36 GEMMs, 4x fewer MACs (f32 error ~1e-5 of the output range instead of ~5e-7).
  * u_pok: (P, cout, cin) = (G g G^T)[p] of the forward kernel, u_pik: (P, cin, cout) of the spatially flipped
  * kernel; both pre-computed once from the frozen weights.
- * workspace >= strotss_conv3x3_winograd_workspace_bytes(h, w, cin, cout, tile_m). */
+ * workspace >= strotss_conv3x3_winograd_workspace_bytes(h, w, cin, cout, tile_m).
+ * u_packed (tile_m = 4 only, may be NULL): the same weights in the MFMA-fragment order written by
+ * strotss_conv3x3_winograd_pack (same number of floats).  With it, layers the three-kernel form would run bound
+ * by its transform traffic (few output channels, many tiles) run as ONE persistent kernel that keeps the
+ * transforms and the 36 GEMMs on chip (csrc/winograd_fused.hip); the workspace is then not touched. */
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m);
+/* u_prk: (36, rows, k) -> u_packed[p][rows/32][k/8][2][32][4]: element (p, r, c) at
+ * ((((p * (rows/32) + r/32) * (k/8) + c/8) * 2 + (c%8)/4) * 32 + r%32) * 4 + c%4.  rows % 32 == 0, k % 8 == 0. */
+int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_packed, void* stream);
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok,
-                                 const float* bias, int cout, int tile_m, float* out, void* workspace,
-                                 size_t workspace_bytes, void* stream);
-int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik, int cin,
-                                   int tile_m, const float* act_in, float* gin, void* workspace,
-                                   size_t workspace_bytes, void* stream);
+                                 const float* u_packed, const float* bias, int cout, int tile_m, float* out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
+                                   const float* u_packed, int cin, int tile_m, const float* act_in, float* gin,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 /* 2x2/2 VALID max-pool: out(h/2, w/2, c). */
 int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, void* stream);
 /* gin(h,w,c) = route gout(h/2,w/2,c) to the first max of each window, times (act > 0) where

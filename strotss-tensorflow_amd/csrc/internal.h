@@ -18,6 +18,7 @@ int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* 
 
 // winograd_fused.hip: F(4x4,3x3) in one kernel (cin % 16 == 0, cout % 32 == 0)
 bool st_winograd43_fused_enabled(int h, int w, int cout);
+int st_winograd43_pack(const float* u_prk, int rows, int k, float* u_packed, hipStream_t st);
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                         const float* mask, int relu, float* out, hipStream_t st);
 

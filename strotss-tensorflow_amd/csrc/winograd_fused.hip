@@ -1,21 +1,22 @@
-// Winograd F(4x4, 3x3) in ONE kernel for the 64-output-channel layers (block1_conv2 forward and data-gradient,
-// data-gradient of block2_conv1; nn/model.py:44-48 of the reference).
+// Winograd F(4x4, 3x3) in ONE persistent kernel for the layers whose three-kernel form (winograd.hip) is bound by
+// its transform traffic (nn/model.py:44-48 of the reference: block1_conv2, block2_conv1/2, ...).
 //
-// The three-kernel form (winograd.hip) moves V = B^T d B and M = V U^T -- each 2.25x the activation -- through
-// HBM: 2.4 GB per launch at 1024^2 x 64 for 0.54 GB of algorithmic traffic, and with Cin = 64 the 36 GEMMs have
-// only 16 flop per byte.  Here a workgroup owns a 4x8 block of Winograd tiles (16x32 output pixels) and 32 of
-// the 64 output channels, and keeps everything on chip:
+// The three-kernel form moves V = B^T d B and M = V U^T -- each 2.25x the activation -- through HBM: 2.4 GB per
+// launch at 1024^2 x 64 for 0.54 GB of algorithmic traffic.  Here a workgroup (768 threads, one per CU) owns work
+// items of 4x8 Winograd tiles (16x32 output pixels) x 32 output channels and keeps everything on chip.  The input
+// channels stream through in chunks of 8, software-pipelined over the chunk stream of ALL the workgroup's items:
 //
-//   for every chunk of 16 input channels:
-//     U    : this wave's 3 positions x (32 couts x 16 ch), straight from L2 into registers (issued first, so the
-//            in-order vmcnt never makes an MFMA wait on the HBM loads behind them)
-//     V    : 36 x (32 tiles x 16 ch) = B^T d B of the 18x34 input patch           LDS -> LDS   (49 KB -> 92 KB)
-//     raw  : the next chunk's patch, global -> registers during the MFMA phase -> LDS
-//     M   += V[p] U[p]^T : 12 waves x 3 positions x 8 v_mfma_f32_32x32x2_f32 (32 tiles x 32 couts per position)
-//   Y = A^T M A : accumulators -> LDS (147 KB) -> bias/ReLU or ReLU mask -> global
+//   phase c:  [issue]  U fragments of chunk c+1 (L2 -> registers), input patch of chunk c+3 (HBM -> registers)
+//             waves 0-3: input transform of chunk c+1:  raw[(c+1)&1] (18x34 px x 8 ch)  ->  V[(c+1)&1] = B^T d B
+//             all waves: M[p] += V[c&1][p] U[p]^T for their 3 of the 36 positions (4 x v_mfma_f32_32x32x2_f32 each)
+//             all waves: patch of chunk c+2 (in flight since phase c-1): registers -> raw[c&1]
+//             ONE barrier
 //
-// HBM traffic = input (x1.2 halo; the second cout half hits L2) + output.  One workgroup of 768 threads per CU
-// (LDS), 48 accumulator registers per lane, 3 waves per SIMD.
+// so the VALU-heavy transform of one wave per SIMD runs under the other waves' MFMAs, and global loads have one
+// (U, L2) or two (patch, HBM) phases to land.  After an item's last chunk the accumulators go through a small LDS
+// exchange buffer one transform-domain column at a time (waves w and w+6 hold column w % 6): Y = A^T M A is
+// accumulated in registers, then bias/ReLU or the ReLU mask, then the stores -- the prefetched V / raw of the next
+// item stay in place.  LDS: V 2 x 36 KB (XOR-swizzled 32-byte rows), raw 2 x 24 KB, exchange 24 KB.
 #include <stdlib.h>
 
 #include "internal.h"
@@ -23,17 +24,44 @@
 
 namespace {
 
-constexpr int F_TR = 4, F_TC = 8;                  // Winograd tiles per workgroup: rows x cols
+#ifdef FUSED_PROF
+__device__ long long fused_prof[2][64][8];
+#define PROF(slot) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && prof_ph < 64) fused_prof[wave >> 2][prof_ph][slot] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PROF(slot) do {} while (0)
+#endif
+// timing ablations for tools/fused_phase_timing.hip (results are wrong when defined)
+#ifdef FUSED_NO_TRANSFORM
+#define ABL_T(x) do {} while (0)
+#else
+#define ABL_T(x) x
+#endif
+#ifdef FUSED_NO_MFMA
+#define MFMA_STEP(av, bv, cv) cv[0] += (av) + (bv)
+#else
+#define MFMA_STEP(av, bv, cv) cv = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, cv, 0, 0, 0)
+#endif
+#ifdef FUSED_NO_RAW
+#define ABL_R(x) do {} while (0)
+#else
+#define ABL_R(x) x
+#endif
+
+constexpr int F_TR = 4, F_TC = 8;                  // Winograd tiles per work item: rows x cols
 constexpr int F_TILES = F_TR * F_TC;               // 32 = M of the MFMA tile
 constexpr int F_PH = 4 * F_TR + 2, F_PW = 4 * F_TC + 2;   // input patch 18 x 34
-constexpr int F_KC = 16;                           // input channels per chunk
-constexpr int F_PS = 20;                           // LDS floats per patch pixel / per V row (80 B: conflict-free b128)
-constexpr int F_RAW = F_PH * F_PW * F_PS;          // 12240 floats
-constexpr int F_V = 36 * F_TILES * F_PS;           // 23040 floats
-constexpr int F_MX = 36 * F_TILES * 32;            // 36864 floats (epilogue exchange, one 32-cout half)
-constexpr int F_LDS_FLOATS = (F_RAW + F_V + 4 > F_MX) ? F_RAW + F_V + 4 : F_MX;   // + dummy slot of store_raw
+constexpr int F_NPX = F_PH * F_PW;                 // 612
+constexpr int F_KC = 8;                            // input channels per chunk
+constexpr int F_PS = 10;                           // LDS floats per patch pixel: tile stride 40 floats, conflict-free
+constexpr int F_RAW = 6 * F_TILES * 32;             // one patch buffer (612 px x 10 + dummy slot), sized to double as an
+                                                   // exchange column in the epilogue
+constexpr int F_V = 36 * F_TILES * F_KC;           // one V buffer: [p][tile][8], 16-byte halves XOR-swizzled by tile
+constexpr int F_SX = 6 * F_TILES * 32;             // exchange buffer: one column of positions x 32 tiles x 32 couts
+constexpr int F_LDS_FLOATS = 2 * F_V + 2 * F_RAW + F_SX;
 constexpr int F_NT = 768;                          // threads: 12 waves, 3 positions each
-constexpr int F_NLOAD = (F_PH * F_PW * 4 + F_NT - 1) / F_NT;   // float4 loads per thread per chunk (4)
+constexpr int F_NLOAD = (F_NPX * 2 + F_NT - 1) / F_NT;    // float4 loads per thread per chunk (2)
+static_assert(F_LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+static_assert(F_RAW >= F_NPX * F_PS + 4 && F_V >= F_SX, "epilogue columns alias the patch / V buffers");
 
 __device__ __forceinline__ void bt6s(float (&d)[6]) {      // in-place B^T d (Lavin & Gray, points 0, +-1, +-2, inf)
   const float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
@@ -45,11 +73,15 @@ __device__ __forceinline__ void bt6s(float (&d)[6]) {      // in-place B^T d (La
   d[5] = 4.f * d1 - 5.f * d3 + d5;
 }
 
-// in: (H, W, K) NHWC; U: (36, Cout, K); out / mask: (H, W, Cout), Cout % 32 == 0.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct ItemRef { int goff[F_NLOAD]; unsigned okm; int g; };
+
+// in: (H, W, K) NHWC, K % 32 == 0; U: fragment-major (36, Cout, K) weights; out / mask: (H, W, Cout), Cout % 32 == 0.
 // !MASK: out = relu ? max(Y + bias, 0) : Y + bias;  MASK: out = mask > 0 ? Y : 0.
 // Work item = (region r of 16x32 output pixels, row-major) x (group g of 32 couts): item = r * NG + g.  The grid is
-// persistent (one workgroup per CU); workgroup b walks the items of its XCD's contiguous range, so the NG groups of
-// a region (same input patch) run on neighbouring CUs of one XCD at the same time and share its L2.
+// persistent; workgroup b walks the items of its XCD's contiguous range, so the NG groups of a region (same input
+// patch) run on neighbouring CUs of one XCD at the same time and share its L2.
 template <bool MASK>
 __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __restrict__ in, int H, int W, int K,
                                                                 const float* __restrict__ U, int Cout,
@@ -57,8 +89,9 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
                                                                 const float* __restrict__ mask, int relu,
                                                                 float* __restrict__ out, int RW, int NG, int nitems) {
   __shared__ __attribute__((aligned(16))) float lds[F_LDS_FLOATS];
-  float* raw = lds;
-  float* Vs = lds + F_RAW;
+  float* const Vb = lds;                            // V[2]
+  float* const Rb = lds + 2 * F_V;                  // raw[2]
+  float* const Sx = lds + 2 * F_V + 2 * F_RAW;      // exchange
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
 
@@ -69,82 +102,112 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
   int item = xcd * per + slot;
   if (item >= item_end) return;                    // whole workgroup
 
-  // ---- raw patch loader of one item: element e = t + 768 i  ->  pixel e >> 2, channel quad e & 3
-  int goff[F_NLOAD];
-  unsigned okm = 0;
-  auto setup = [&](int it, int (&go)[F_NLOAD], unsigned& ok_mask) {
+  // ---- patch loader of one item: element e = t + 768 i  ->  pixel e >> 1, channel quad e & 1
+  auto setup = [&](int it, ItemRef& r) {
     const int region = it / NG;
+    r.g = it - region * NG;
     const int ry = region / RW, rx = region - ry * RW;
-    ok_mask = 0;
+    r.okm = 0;
 #pragma unroll
     for (int i = 0; i < F_NLOAD; ++i) {
       const int e = t + F_NT * i;
-      const int px = e >> 2, c4 = e & 3;
+      const int px = e >> 1, c4 = e & 1;
       const int py = px / F_PW, pxx = px - py * F_PW;
       const int gy = ry * (4 * F_TR) - 1 + py, gx = rx * (4 * F_TC) - 1 + pxx;
-      const bool ok = (e < F_PH * F_PW * 4) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      ok_mask |= (unsigned)ok << i;
-      go[i] = ok ? (gy * W + gx) * K + c4 * 4 : 0;     // out-of-image: load pixel 0, zeroed at the LDS store
+      const bool ok = (e < F_NPX * 2) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      r.okm |= (unsigned)ok << i;
+      r.goff[i] = ok ? (gy * W + gx) * K + c4 * 4 : 0;   // out-of-image: load pixel 0, zeroed at the LDS store
     }
   };
-  f32x4 stage[F_NLOAD];
-  auto load_raw = [&](const int (&go)[F_NLOAD], int kc) {
+  auto load_raw = [&](const ItemRef& r, int kc, f32x4 (&st)[F_NLOAD]) {
 #pragma unroll
-    for (int i = 0; i < F_NLOAD; ++i) stage[i] = *reinterpret_cast<const f32x4*>(in + go[i] + kc * F_KC);
+    for (int i = 0; i < F_NLOAD; ++i) st[i] = *reinterpret_cast<const f32x4*>(in + r.goff[i] + kc * F_KC);
   };
-  auto store_raw = [&](unsigned ok_mask) {         // branch-free: surplus threads write a dummy slot behind V
+  auto store_raw = [&](float* raw, unsigned okm, const f32x4 (&st)[F_NLOAD]) {   // branch-free (dummy slot at the end)
 #pragma unroll
     for (int i = 0; i < F_NLOAD; ++i) {
       const int e = t + F_NT * i;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const int o = (e < F_PH * F_PW * 4) ? (e >> 2) * F_PS + (e & 3) * 4 : F_RAW + F_V;
-      *reinterpret_cast<f32x4*>(raw + o) = ((ok_mask >> i) & 1u) ? stage[i] : z;
+      const int o = (e < F_NPX * 2) ? (e >> 1) * F_PS + (e & 1) * 4 : F_NPX * F_PS;
+      const bool ok = (okm >> i) & 1u;
+      f32x2 lo = {ok ? st[i][0] : 0.f, ok ? st[i][1] : 0.f}, hi = {ok ? st[i][2] : 0.f, ok ? st[i][3] : 0.f};
+      *reinterpret_cast<f32x2*>(raw + o) = lo;      // 40-byte pixel stride: 8-byte aligned only
+      *reinterpret_cast<f32x2*>(raw + o + 2) = hi;
     }
   };
-  // ---- input transform: thread (< 512) = (tile t >> 4, channel t & 15)
-  auto transform = [&]() {
-    const int ttile = t >> 4, tch = t & 15;
+  // ---- input transform, all 12 waves: thread = (tile, channel PAIR) of item t & 127 and ONE output row
+  // r = t >> 7 (wave-uniform) of V = B^T d B.  On gfx950 the f32 MFMA and the VALU do not co-execute (measured:
+  // tools/mfma_valu_overlap.hip -- a v_fma loop in one wave and a v_mfma_f32_32x32x2 loop in another wave of the
+  // same SIMD take the SUM of their times), so every VALU instruction is paid in MFMA time: two channels per lane
+  // make the whole transform packed-f32 (v_pk_fma/add/mul) without register shuffles, a third of the scalar count.
+  auto transform = [&](const float* raw, float* V) {     // threads 0..255: (tile, channel pair, half of the rows)
+    const int it = t & 127, half = (t >> 7) & 1;
+    const int ttile = it >> 2, pr = it & 3;
     const int tty = ttile >> 3, ttx = ttile & 7;
-    float d[6][6];
-    const float* src = raw + ((4 * tty) * F_PW + 4 * ttx) * F_PS + tch;
+    const float* src = raw + ((4 * tty) * F_PW + 4 * ttx) * F_PS + 2 * pr;
+    auto ld = [&](int k, int q) { return *reinterpret_cast<const f32x2*>(src + (k * F_PW + q) * F_PS); };
+    float* dst = V + (size_t)(18 * half) * (F_TILES * F_KC) + ttile * F_KC + ((((pr >> 1) ^ (ttile >> 3)) & 1) << 2) +
+                 ((pr & 1) << 1);
+    auto row_out = [&](int r, const f32x2 (&tr)[6]) {
+      const f32x2 d0 = tr[0], d1 = tr[1], d2 = tr[2], d3 = tr[3], d4 = tr[4], d5 = tr[5];
+      f32x2 v[6];
+      v[0] = 4.f * d0 - 5.f * d2 + d4;
+      v[1] = -4.f * d1 - 4.f * d2 + d3 + d4;
+      v[2] = 4.f * d1 - 4.f * d2 - d3 + d4;
+      v[3] = -2.f * d1 - d2 + 2.f * d3 + d4;
+      v[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
+      v[5] = 4.f * d1 - 5.f * d3 + d5;
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+      for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x2*>(dst + (6 * r + q) * (F_TILES * F_KC)) = v[q];
+    };
+    f32x2 ta[6], tb[6], tc[6];
+    if (half == 0) {                                // rows 0, 1, 2 from input rows 0..4
 #pragma unroll
-      for (int q = 0; q < 6; ++q) d[r][q] = src[(r * F_PW + q) * F_PS];
+      for (int q = 0; q < 6; ++q) {
+        const f32x2 d0 = ld(0, q), d1 = ld(1, q), d2 = ld(2, q), d3 = ld(3, q), d4 = ld(4, q);
+        ta[q] = 4.f * d0 - 5.f * d2 + d4;
+        tb[q] = -4.f * d1 - 4.f * d2 + d3 + d4;
+        tc[q] = 4.f * d1 - 4.f * d2 - d3 + d4;
+      }
+    } else {                                        // rows 3, 4, 5 from input rows 1..5
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      float col[6] = {d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]};
-      bt6s(col);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) d[r][q] = col[r];
+      for (int q = 0; q < 6; ++q) {
+        const f32x2 d1 = ld(1, q), d2 = ld(2, q), d3 = ld(3, q), d4 = ld(4, q), d5 = ld(5, q);
+        ta[q] = -2.f * d1 - d2 + 2.f * d3 + d4;
+        tb[q] = 2.f * d1 - d2 - 2.f * d3 + d4;
+        tc[q] = 4.f * d1 - 5.f * d3 + d5;
+      }
     }
-    float* dst = Vs + ttile * F_PS + tch;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      bt6s(d[r]);
-#pragma unroll
-      for (int q = 0; q < 6; ++q) dst[(r * 6 + q) * (F_TILES * F_PS)] = d[r][q];
-    }
+    row_out(0, ta); row_out(1, tb); row_out(2, tc);
   };
-  // U fragments of (item, chunk): positions wave, wave + 12, wave + 24; B = U[p][32 g + l31][16 kc + 8 hh ..]
-  const size_t b_step = (size_t)12 * Cout * K;
-  auto load_u = [&](int it, int kc, f32x4 (&b)[3][2]) {
-    const int g = it - (it / NG) * NG;
-    const float* bp = U + ((size_t)wave * Cout + g * 32 + l31) * K + 8 * hh + kc * F_KC;
+  // U fragments: positions wave, wave + 12, wave + 24; B = U[p][32 g + l31][8 kc + 4 hh ..] from the fragment-major
+  // copy (strotss_conv3x3_winograd_pack): one fully coalesced 1 KB wave load per (position, group, chunk).  From the
+  // (P, Cout, K) layout every load would touch 32 cache lines for 32 bytes each, and the per-XCD L2 request rate
+  // (all 32 CUs stream the same weights) becomes the bound.
+  const int nchunk = K / F_KC;                      // even, >= 4
+  const size_t b_step = (size_t)12 * NG * nchunk * 256;
+  auto load_u = [&](int g, int kc, f32x4 (&b)[3]) {
+    const float* bp = U + (((size_t)wave * NG + g) * nchunk + kc) * 256 + lane * 4;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      b[j][0] = *reinterpret_cast<const f32x4*>(bp + j * b_step);
-      b[j][1] = *reinterpret_cast<const f32x4*>(bp + j * b_step + 4);
-    }
+    for (int j = 0; j < 3; ++j) b[j] = *reinterpret_cast<const f32x4*>(bp + j * b_step);
   };
-  const float* a_base = Vs + (wave * F_TILES + l31) * F_PS + 8 * hh;      // A = V[p][tile l31][8 hh ..]
-  constexpr int a_step = 12 * F_TILES * F_PS;
-  const int nchunk = K / F_KC;
+  // A = V[p][tile l31][4 (hh ^ swizzle) ..]
+  const int a_off = (wave * F_TILES + l31) * F_KC + (((hh ^ (l31 >> 3)) & 1) << 2);
+  constexpr int a_step = 12 * F_TILES * F_KC;
 
-  f32x4 b[3][2];
-  setup(item, goff, okm);
-  load_raw(goff, 0);
-  store_raw(okm);
+  int prof_ph = 0; (void)prof_ph;
+  ItemRef cur, nxt;
+  setup(item, cur);
+  f32x4 S0[F_NLOAD], S1[F_NLOAD];                   // patches in flight: S[c & 1] is loaded in phase c with chunk c + 3
+  f32x4 b0[3], b1[3];                              // U fragments: b0 for even chunks, b1 for odd ones
+  // ---- prologue: raw[0] = chunk 0, raw[1] = chunk 1, V[0] = T(chunk 0), S1 = chunk 2 in flight, b = U(chunk 0)
+  load_raw(cur, 0, S0);
+  load_raw(cur, 1, S1);
+  store_raw(Rb, cur.okm, S0);
+  store_raw(Rb + F_RAW, cur.okm, S1);
+  load_u(cur.g, 0, b0);
+  load_raw(cur, 2, S1);
+  __syncthreads();
+  if (t < 256) transform(Rb, Vb);
   __syncthreads();
 
   for (;;) {
@@ -155,121 +218,194 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int next = item + nslot;
     const bool more = next < item_end;              // uniform
+    if (more) setup(next, nxt); else nxt = cur;     // past the last item the pipeline re-reads it (results unused)
 
-    for (int kc = 0; kc < nchunk; ++kc) {
-      // This chunk's U fragments (they land during the transform), then -- after the transform, whose registers
-      // they would otherwise compete with -- the input patch of the NEXT chunk (of the next item after the last
-      // chunk; the very last chunk of the workgroup re-loads itself).  vmcnt retires in order, so the MFMAs wait
-      // for the older U loads only and the patch has the MFMA phase to land.  Loads and LDS stores are
-      // unconditional: behind a branch the compiler sinks them below the MFMAs.
-      const bool last = kc + 1 == nchunk;
-      load_u(item, kc, b);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t < 512) transform();
-      if (last && more) setup(next, goff, okm);     // this item's patches are all loaded
-      load_raw(goff, last ? (more ? 0 : kc) : kc + 1);
-      __syncthreads();                              // V complete; raw consumed
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 a[3][2];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        a[j][0] = *reinterpret_cast<const f32x4*>(a_base + j * a_step);
-        a[j][1] = *reinterpret_cast<const f32x4*>(a_base + j * a_step + 4);
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][0][s], b[j][0][s], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][1][s], b[j][1][s], acc[j], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);            // keep the patch's zero-selects (which wait for it) behind the MFMAs
-      if (!last) store_raw(okm);                    // after the last chunk the patch buffer becomes the exchange area
-      __syncthreads();                              // all waves done with V; next raw complete
+    // stream offset d from chunk kc of the current item -> (item ref, chunk)
+#define CHUNK_AT(d, ref, kk)                             \
+    const bool wrap_##d = kc + d >= nchunk;              \
+    const ItemRef& ref = wrap_##d ? nxt : cur;           \
+    const int kk = kc + d - (wrap_##d ? nchunk : 0);
+#define PHASE(PAR, SLOAD, SSTORE, BCUR, BNEXT)                                                                            \
+    {                                                                                                         \
+      PROF(0);                                                                                                \
+      CHUNK_AT(1, r1, k1) CHUNK_AT(3, r3, k3)                                                                 \
+      const unsigned okm2 = (kc + 2 >= nchunk) ? nxt.okm : cur.okm;                                           \
+      load_u(r1.g, k1, BNEXT);                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      PROF(1);                                                                                                \
+      const float* Vc = Vb + PAR * F_V + a_off;                                                               \
+      f32x4 a[3];                                                                                             \
+      /* the middle wave of each SIMD runs its MFMAs first, the other two transform first: the phase's VALU */ \
+      /* and MFMA halves of different waves then overlap instead of all waves fighting for the same pipe  */   \
+      if (t < 256) ABL_T(transform(Rb + (1 - PAR) * F_RAW, Vb + (1 - PAR) * F_V));                            \
+      PROF(2);                                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j) a[j] = *reinterpret_cast<const f32x4*>(Vc + j * a_step);  \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                           \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                         \
+          MFMA_STEP(a[j][s], BCUR[j][s], acc[j]);                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      PROF(3);                                                                                                \
+      /* the patch loads (32 cache lines per wave instruction) go here, not to the phase start: 24 of them */ \
+      /* queued in the CU's address unit right after the barrier stall every wave behind them             */ \
+      ABL_R(load_raw(r3, k3, SLOAD));                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      ABL_R(store_raw(Rb + PAR * F_RAW, okm2, SSTORE));                                                       \
+      PROF(4);                                                                                                \
+      __syncthreads();                                                                                        \
+      PROF(5);                                                                                                \
+      ++prof_ph;                                                                                              \
+      ++kc;                                                                                                   \
     }
+    for (int kc = 0; kc < nchunk;) {
+      PHASE(0, S0, S1, b0, b1)
+      PHASE(1, S1, S0, b1, b0)
+    }
+#undef PHASE
+#undef CHUNK_AT
 
-    // ---- output transform through LDS: Mx[p][tile][32 couts]
-    const int region = item / NG, g = item - region * NG;
+    PROF(0);
+    // ---- output transform by columns q of the 6x6 positions: waves q and q + 6 hold its rows {0,2,4} / {1,3,5}
+    const int region = item / NG;
     const int ry = region / RW, rx = region - ry * RW;
     const int y0 = ry * (4 * F_TR), x0 = rx * (4 * F_TC);
-    float* Mx = lds;
+    float Y[2][4][4];                               // starts at the bias (none for the data-gradient)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float* dst = Mx + ((wave + 12 * j) * F_TILES + 4 * hh) * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * 32] = acc[j][r];
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int e = t; e < F_TILES * 32; e += F_NT) {
-      const int cl = e & 31, tile = e >> 5;
-      const int ty = tile >> 3, tx = tile & 7;
-      const int co = g * 32 + cl;
-      const float* src = Mx + tile * 32 + cl;
-      float s[4][6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        float m[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) m[r] = src[(r * 6 + q) * (F_TILES * 32)];
-        s[0][q] = m[0] + m[1] + m[2] + m[3] + m[4];
-        s[1][q] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
-        s[2][q] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
-        s[3][q] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
-      }
+    for (int i = 0; i < 2; ++i) {
       float bv = 0.f;
-      if constexpr (!MASK) { if (bias) bv = bias[co]; }   // the plain data-gradient has neither bias nor mask
-      const int yb = y0 + 4 * ty, xb = x0 + 4 * tx;
-      // branch-free: rows / columns beyond the image are clamped for the (batched) mask loads and predicated
-      // at the stores, so no load or store waits on another
-      const bool tile_in = yb < H && xb < W;
-      const size_t ob = tile_in ? ((size_t)yb * W + xb) * Cout + co : (size_t)co;
-      int off[4][4];
-      bool ok[4][4];
+      if constexpr (!MASK) { if (bias && t < 512) bv = bias[cur.g * 32 + (t & 31)]; }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ok[r][q] = tile_in && yb + r < H && xb + q < W;
-          off[r][q] = ok[r][q] ? (r * W + q) * Cout : 0;
+        for (int q = 0; q < 4; ++q) Y[i][r][q] = bv;
+    }
+    // Three columns per round: besides Sx, V[1] (read by the last phase's MFMAs) and raw[0] (transformed in the
+    // last phase) are free here -- nchunk is even, so an item always ends on an odd phase.
+    const int myq = wave % 6, myr = wave / 6;
+    float* const colbuf[3] = {Sx, Vb + F_V, Rb};
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      if (myq / 3 == round) {
+        float* base = colbuf[0];
+        if (myq % 3 == 1) base = colbuf[1];
+        if (myq % 3 == 2) base = colbuf[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float* dst = base + ((myr + 2 * j) * F_TILES + 4 * hh) * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * 32] = acc[j][r];
         }
-      float* op = out + ob;
-      float mk[4][4];
-      if constexpr (MASK) {
-        const float* mp = mask + ob;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) mk[r][q] = mp[off[r][q]];
       }
+      __syncthreads();
+      if (round == 0) PROF(1); else PROF(3);
+      if (t < 512) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float yv[4];
-        yv[0] = s[r][0] + s[r][1] + s[r][2] + s[r][3] + s[r][4] + bv;
-        yv[1] = s[r][1] - s[r][2] + 2.f * s[r][3] - 2.f * s[r][4] + bv;
-        yv[2] = s[r][1] + s[r][2] + 4.f * s[r][3] + 4.f * s[r][4] + bv;
-        yv[3] = s[r][1] - s[r][2] + 8.f * s[r][3] - 8.f * s[r][4] + s[r][5] + bv;
+        for (int i = 0; i < 2; ++i) {
+          const int e = t + 512 * i;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = yv[q];
-          if constexpr (MASK) v = mk[r][q] > 0.f ? v : 0.f;
-          else if (relu) v = fmaxf(v, 0.f);
-          if (ok[r][q]) op[off[r][q]] = v;
+          for (int k = 0; k < 3; ++k) {
+            const int q = 3 * round + k;
+            const float* src = colbuf[k] + (e >> 5) * 32 + (e & 31);      // [row][tile][cout]
+            float m[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) m[r] = src[r * (F_TILES * 32)];
+            float sv[4];
+            sv[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+            sv[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+            sv[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+            sv[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+            // Y[r][:] += s[r] * A^T[:, q]
+            constexpr float AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f},
+                                        {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (AT[c][q] != 0.f) Y[i][r][c] += AT[c][q] * sv[r];
+          }
+        }
+      }
+      __syncthreads();
+      if (round == 0) PROF(2); else PROF(4);
+    }
+    if (t < 512) {
+      const float lo = (!MASK && relu) ? 0.f : -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = t + 512 * i;
+        const int cl = e & 31, tile = e >> 5;
+        const int ty = tile >> 3, tx = tile & 7;
+        const int co = cur.g * 32 + cl;
+        const int yb = y0 + 4 * ty, xb = x0 + 4 * tx;
+        // Every memory-dependent value (bias: folded into Y before the rounds; ReLU mask: one batch of clamped
+        // loads condensed to a bit mask) is resolved before the first store, so the stores carry no s_waitcnt --
+        // with a load pending the compiler puts vmcnt(0) in front of each predicated store and they serialise.
+        const bool tile_in = yb < H && xb < W, full = yb + 3 < H && xb + 3 < W;
+        const size_t ob = tile_in ? ((size_t)yb * W + xb) * Cout + co : (size_t)co;
+        float* op = out + ob;
+        unsigned keep = 0xffffu;
+        if constexpr (MASK) {
+          const float* mp = mask + ob;
+          float mk[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const bool ok = tile_in && yb + r < H && xb + c < W;
+              mk[r][c] = mp[ok ? (r * W + c) * Cout : 0];
+            }
+          keep = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) keep |= (mk[r][c] > 0.f ? 1u : 0u) << (4 * r + c);
+        }
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              op[(r * W + c) * Cout] = ((keep >> (4 * r + c)) & 1u) ? fmaxf(Y[i][r][c], lo) : 0.f;
+        } else if (tile_in) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (yb + r < H && xb + c < W)
+                op[(r * W + c) * Cout] = ((keep >> (4 * r + c)) & 1u) ? fmaxf(Y[i][r][c], lo) : 0.f;
         }
       }
     }
+    PROF(5); PROF(6); ++prof_ph;
     if (!more) break;
-    __syncthreads();                                // exchange area read; it becomes the patch buffer again
     item = next;
-    store_raw(okm);                                 // the next item's first patch, loaded during the last chunk
-    __syncthreads();
+    cur = nxt;
+  }
+}
+
+__global__ __launch_bounds__(256) void winograd43_pack_kernel(const float* __restrict__ u, int rows, int k, size_t total,
+                                                             float* __restrict__ up) {
+  const int ng = rows / 32, nc = k / F_KC;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % k);
+    const size_t pr = e / k;
+    const int r = (int)(pr % rows), p = (int)(pr / rows);
+    const size_t o = (((((size_t)p * ng + r / 32) * nc + c / 8) * 2 + (c % 8) / 4) * 32 + r % 32) * 4 + c % 4;
+    up[o] = u[e];
   }
 }
 
 }  // namespace
 
+int st_winograd43_pack(const float* u_prk, int rows, int k, float* u_packed, hipStream_t st) {
+  const size_t total = (size_t)36 * rows * k;
+  hipLaunchKernelGGL(winograd43_pack_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, st,
+                     u_prk, rows, k, total, u_packed);
+  ST_LAUNCH_RET();
+}
+
 // Policy (measured per layer, tools/conv_bench.py): the fused kernel wins where the three-kernel form is bound by
-// its transform traffic -- up to 128 output channels -- and there are at least two work items per CU.
+// its transform traffic -- up to 256 output channels -- and there are at least two work items per CU.
 // STROTSS_WINO_FUSED: 0 = never, 1 (default) = that policy, 2 = every layer it supports.
 bool st_winograd43_fused_enabled(int h, int w, int cout) {
   static int on = -1;
@@ -278,13 +414,13 @@ bool st_winograd43_fused_enabled(int h, int w, int cout) {
   if (on >= 2) return true;
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const long items = (long)((TH + F_TR - 1) / F_TR) * ((TW + F_TC - 1) / F_TC) * (cout / 32);
-  return cout <= 128 && items >= 512;
+  return cout <= 256 && items >= 512;
 }
 
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                         const float* mask, int relu, float* out, hipStream_t st) {
-  if (cin % F_KC != 0 || cout % 32 != 0) return STROTSS_EALIGN;
-  if ((size_t)h * w * cin >= ((size_t)1 << 31) || (size_t)h * w * cout >= ((size_t)1 << 31)) return STROTSS_EALIGN;
+  if (cin % 32 != 0 || cout % 32 != 0) return STROTSS_EALIGN;
+  if ((size_t)h * w * cin >= ((size_t)1 << 30) || (size_t)h * w * cout >= ((size_t)1 << 30)) return STROTSS_EALIGN;
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const int RH = (TH + F_TR - 1) / F_TR, RW = (TW + F_TC - 1) / F_TC;
   const int NG = cout / 32, nitems = RH * RW * NG;

@@ -105,6 +105,28 @@ def _tile_m(u: torch.Tensor) -> int:
     return {16: 2, 36: 4}[int(u.shape[0])]
 
 
+_packed = {}       # id(u) -> (weakref(u), packed): fragment-major copies of frozen F(4x4,3x3) weights
+
+
+def winograd_packed(u: torch.Tensor):
+    """The fragment-major copy of a (36, rows, k) Winograd weight tensor for the fused kernel (made once per
+    tensor object; the weights are frozen), or None where the fused kernel does not apply."""
+    import weakref
+    if int(u.shape[0]) != 36 or int(u.shape[1]) % 32 or int(u.shape[2]) % 32:
+        return None
+    hit = _packed.get(id(u))
+    if hit is not None and hit[0]() is u:
+        return hit[1]
+    require(u, "winograd weights")
+    up = torch.empty_like(u)
+    check(_hip.lib().strotss_conv3x3_winograd_pack(ptr(u), int(u.shape[1]), int(u.shape[2]), ptr(up), stream_ptr()),
+          "conv3x3_winograd_pack")
+    for k in [k for k, v in _packed.items() if v[0]() is None]:
+        del _packed[k]
+    _packed[id(u)] = (weakref.ref(u), up)
+    return up
+
+
 def conv3x3_winograd_fwd(x, u_pok, bias, out=None):
     """u_pok: (16, cout, cin) -> F(2x2,3x3), (36, cout, cin) -> F(4x4,3x3)."""
     require(x, "conv input"); h, w, cin = hwc(x)
@@ -113,8 +135,8 @@ def conv3x3_winograd_fwd(x, u_pok, bias, out=None):
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
     m = _tile_m(u_pok)
     ws, nb = _wino_ws(h, w, cin, cout, m, x.device)
-    check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(bias), cout, m, ptr(out),
-                                                  ptr(ws), nb, stream_ptr()), "conv3x3_winograd_fwd")
+    check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(winograd_packed(u_pok)), ptr(bias),
+                                                  cout, m, ptr(out), ptr(ws), nb, stream_ptr()), "conv3x3_winograd_fwd")
     return out
 
 
@@ -124,8 +146,9 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
         out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
     m = _tile_m(u_pik)
     ws, nb = _wino_ws(h, w, cout, cin, m, gout.device)
-    check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), cin, m, ptr(act_in), ptr(out),
-                                                    ptr(ws), nb, stream_ptr()), "conv3x3_winograd_dgrad")
+    check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), ptr(winograd_packed(u_pik)), cin,
+                                                    m, ptr(act_in), ptr(out), ptr(ws), nb, stream_ptr()),
+          "conv3x3_winograd_dgrad")
     return out
 
 

@@ -32,14 +32,19 @@ __device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, int l
 // ---------------------------------------------------------------- epilogues
 struct EpiCosDist {  // C = 1 - acc * (ra[i]*rb[j])      (losses.py:12-15)
   const float* ra; const float* rb; float* C; int ldc; int M, N;
+  int symm;            // x == y: only tiles on or above the diagonal are computed, the rest is mirrored (bitwise equal)
+  static constexpr bool SYMM = true;
   __device__ __forceinline__ void set_batch(int) {}
+  __device__ __forceinline__ float value(int r, int c, float v) const { return 1.0f - v * (ra[r] * rb[c]); }
   __device__ __forceinline__ float apply(int r, int c, float v) const {
-    if (r < M && c < N) C[(size_t)r * ldc + c] = 1.0f - v * (ra[r] * rb[c]);
+    if (r < M && c < N) C[(size_t)r * ldc + c] = value(r, c, v);
     return 0.f;
   }
+  __device__ __forceinline__ void mirror(int r, int c, float val) const { C[(size_t)r * ldc + c] = val; }
   __device__ __forceinline__ void finish(float*, float) const {}
 };
 struct EpiScaleStore {  // C = alpha * acc   (batched: C += z * strideC)
+  static constexpr bool SYMM = false;
   float* C; int ldc; int M, N; float alpha; long long strideC;
   __device__ __forceinline__ void set_batch(int z) { C += (long long)z * strideC; }
   __device__ __forceinline__ float apply(int r, int c, float v) const {
@@ -49,6 +54,7 @@ struct EpiScaleStore {  // C = alpha * acc   (batched: C += z * strideC)
   __device__ __forceinline__ void finish(float*, float) const {}
 };
 struct EpiAxpbyBias {  // C = alpha*acc + C + bias[c]
+  static constexpr bool SYMM = false;
   float* C; int ldc; int M, N; float alpha; const float* bias; float bias_scale;
   __device__ __forceinline__ void set_batch(int) {}
   __device__ __forceinline__ float apply(int r, int c, float v) const {
@@ -61,8 +67,13 @@ struct EpiAxpbyBias {  // C = alpha*acc + C + bias[c]
   __device__ __forceinline__ void finish(float*, float) const {}
 };
 // moment_matching forward (losses.py:49-52): diff = acc/n - Sx; T = sign(diff); sum |diff|.
+// Both covariances are bitwise symmetric (same k order for (i,j) and (j,i)): tiles below the diagonal are skipped,
+// their T entries mirrored and their |diff| counted by doubling the tile above.
 struct EpiMomentFwd {
+  static constexpr bool SYMM = true;
+  static constexpr int symm = 1;
   const float* Sx; float* T; int ld; int M, N; float inv_n; float* partial;
+  __device__ __forceinline__ float value(int r, int c, float v) const { return signf(v * inv_n - Sx[(size_t)r * ld + c]); }
   __device__ __forceinline__ float apply(int r, int c, float v) const {
     if (r < M && c < N) {
       const size_t o = (size_t)r * ld + c;
@@ -72,13 +83,15 @@ struct EpiMomentFwd {
     }
     return 0.f;
   }
+  __device__ __forceinline__ void mirror(int r, int c, float val) const { T[(size_t)r * ld + c] = val; }
   __device__ __forceinline__ void finish(float* red, float local) const {
-    const float s = block_sum_256(local, red);
+    const float s = block_sum_256(blockIdx.x > blockIdx.y ? 2.f * local : local, red);
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s;   // (two-barrier kernel: 2-D grid)
   }
 };
 // self_similarity backward: dX[i,d] += g * r_i * (acc - xhat[i,d] * q_i), xhat = x * r_i
 struct EpiSelfsimBwd {
+  static constexpr bool SYMM = false;
   const float* x; const float* r; const float* q; float* dx; int ld; int M, N; float g;
   __device__ __forceinline__ float apply(int row, int c, float v) const {
     if (row < M && c < N) {
@@ -91,6 +104,19 @@ struct EpiSelfsimBwd {
   __device__ __forceinline__ void finish(float*, float) const {}
 };
 
+// Writes the transpose of this workgroup's BM x BN tile (values val(r, c)) to (c, r) through LDS so that the mirrored
+// stores are row-contiguous.  `tile` holds >= BM * (BN + 1) floats.
+template <int BM, int BN, int NT, class Epi, class Val>
+__device__ __forceinline__ void mirror_tile(const Epi& epi, float* tile, int m0, int n0, int M, int N, Val val) {
+  __syncthreads();                                  // operands in LDS are dead
+  val([&](int r, int c, float v) { tile[(r - m0) * (BN + 1) + (c - n0)] = v; });
+  __syncthreads();
+  for (int i = threadIdx.x; i < BM * BN; i += NT) {
+    const int c = i / BM, r = i - c * BM;           // consecutive lanes: consecutive r = contiguous in the mirrored row
+    if (m0 + r < M && n0 + c < N) epi.mirror(n0 + c, m0 + r, tile[r * (BN + 1) + c]);
+  }
+}
+
 template <int BM, int BN, bool AKC, bool BKC, class Epi>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, int M,
                                                    const float* __restrict__ B, int ldb, int N, int K,
@@ -99,6 +125,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
   float* ldsA = lds;
   float* ldsB = lds + OperandLds<BM>::floats;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if constexpr (Epi::SYMM) {
+    if (epi.symm && n0 < m0) { epi.finish(lds, 0.f); return; }      // mirrored by the tile above the diagonal
+  }
   f32x16 acc[BM / 64][BN / 64];
   acc_zero<BM, BN>(acc);
   gemm_mainloop<BM, BN, AKC, BKC>(A, lda, M, B, ldb, N, K, m0, n0, ldsA, ldsB, acc);
@@ -111,6 +140,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
         local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
+  if constexpr (Epi::SYMM) {
+    static_assert(!Epi::SYMM || OperandLds<BM>::floats + OperandLds<BN>::floats >= BM * (BN + 1), "mirror tile");
+    if (epi.symm && n0 > m0)
+      mirror_tile<BM, BN, 256>(epi, lds, m0, n0, M, N, [&](auto put) {
+#pragma unroll
+        for (int im = 0; im < BM / 64; ++im)
+#pragma unroll
+          for (int in = 0; in < BN / 64; ++in)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int r = m0 + map.row(im, reg), c = n0 + map.colof(in);
+              put(r, c, (r < M && c < N) ? epi.value(r, c, acc[im][in][reg]) : 0.f);
+            }
+      });
+  }
   epi.finish(lds, local);
 }
 
@@ -129,6 +173,9 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kc_pipe_kernel(const float* __re
   B += (long long)bz * strideB;
   epi.set_batch(bz);
   const int m0 = (rem / gx) * Cfg::BM, n0 = (rem % gx) * Cfg::BN;
+  if constexpr (Epi::SYMM) {
+    if (epi.symm && n0 < m0) return;                // mirrored by the tile above the diagonal
+  }
   RowMajorLoader<Cfg, Cfg::NA> la(A, lda, m0, M, K);
   RowMajorLoader<Cfg, Cfg::NB> lb(B, ldb, n0, N, K);
   f32x16 acc[Cfg::TM][Cfg::TN];
@@ -148,6 +195,21 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kc_pipe_kernel(const float* __re
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
         local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
+  if constexpr (Epi::SYMM) {
+    static_assert(!Epi::SYMM || Cfg::LDS_FLOATS >= Cfg::BM * (Cfg::BN + 1), "mirror tile");
+    if (epi.symm && n0 > m0)
+      mirror_tile<Cfg::BM, Cfg::BN, Cfg::NT>(epi, lds, m0, n0, M, N, [&](auto put) {
+#pragma unroll
+        for (int im = 0; im < Cfg::TM; ++im)
+#pragma unroll
+          for (int in = 0; in < Cfg::TN; ++in)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int r = m0 + map.row(im, reg), c = n0 + map.colof(in);
+              put(r, c, (r < M && c < N) ? epi.value(r, c, acc[im][in][reg]) : 0.f);
+            }
+      });
+  }
   __syncthreads();
   epi.finish(lds, local);
 }
@@ -257,7 +319,7 @@ int launch(const float* A, int lda, int M, const float* B, int ldb, int N, int K
 // C[i,j] = 1 - <x_i, y_j> rx[i] ry[j]
 int st_cosine_distance(const float* x, const float* rx, int nx, const float* y, const float* ry, int ny,
                        int ld, float* C, int ldc, hipStream_t s) {
-  EpiCosDist e{rx, ry, C, ldc, nx, ny};
+  EpiCosDist e{rx, ry, C, ldc, nx, ny, (x == y && rx == ry && nx == ny) ? 1 : 0};
   return launch_pipe<64, 64>(x, ld, nx, 0, y, ld, ny, 0, ld, 1, e, s);
 }
 

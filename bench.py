@@ -10,7 +10,8 @@ sampling -> self-similarity / moment / REMD / palette losses -> backward -> RMSp
 configuration BASELINE.json's metric is quoted on.  Inputs (images, frozen weights, style
 statistics, the index stream) are resident in HBM before the timed region; fp32 throughout (the
 reference's dtype; the MFMA used is the exact-f32 one).  With N > 1 every rank optimises its own
-pair (replicas, no collective on the data path) and `value` is the sum.
+pair (replicas, no collective on the data path) and `value` is the sum.  `--mode strips` instead shards
+ONE pair over the N GPUs by image strips (nn/parallel.py; strong scaling, `value` = steps/s of that one job).
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      : the dominant kernel (3x3 conv implicit GEMM on the fp32 MFMA): algorithmic FLOP of
@@ -58,7 +59,7 @@ def conv_flops(params, h, w):
     return total
 
 
-def build_engine(params, scale, dev, seed, sample_size=SAMPLES):
+def build_engine(params, scale, dev, seed, sample_size=SAMPLES, strips=None):
     from nn import _ops, engine, strotss_utils as SU
     content = synth_image(scale, scale, 100 + seed).to(dev)
     style = synth_image(scale, scale, 200 + seed).to(dev)
@@ -72,7 +73,7 @@ def build_engine(params, scale, dev, seed, sample_size=SAMPLES):
     init = SU.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
     alpha = 1.0            # alpha at the 5th scale of the schedule 16, 8, 4, 2, 1
     eng = engine.StepEngine(params, cfeat, [target], init, alpha, 2.0 + alpha + 1.0 / max(alpha, 1.0), 1e-3,
-                            sample_size=sample_size)
+                            sample_size=sample_size, strips=strips)
     return eng, rng
 
 
@@ -80,6 +81,13 @@ def index_stream(scale, count, rng, dev, sample_size=SAMPLES):
     from nn import strotss_utils as SU
     arr = np.stack([SU.make_indices_np(scale, scale, True, sample_size, rng) for _ in range(count)])
     return torch.from_numpy(arr).to(dev)
+
+
+def strip_index_stream(scale, count, rng, dev, plan, sample_size=SAMPLES):
+    """index sets ordered by owning rank + their block offsets (identical on every rank: same seed)"""
+    from nn import parallel as par, strotss_utils as SU
+    sets = [par.sort_indices_by_strip(SU.make_indices_np(scale, scale, True, sample_size, rng), plan) for _ in range(count)]
+    return torch.from_numpy(np.stack([s[0] for s in sets])).to(dev), [s[1] for s in sets]
 
 
 def run_steps(eng, idx, first, count):
@@ -245,6 +253,9 @@ def main():
     ap.add_argument("--no-pyramid", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-output run of the whole CLI schedule")
+    ap.add_argument("--mode", choices=("replicas", "strips"), default="replicas",
+                    help="N > 1: independent pairs per GPU (default, weak scaling) or ONE pair sharded by image strips "
+                         "(strong scaling: value = steps/s of that one job)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,7 +264,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("STROTSS_DIST_BACKEND", "nccl")     # gloo: rehearsal of N ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            local_rank %= max(1, torch.cuda.device_count())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
@@ -262,8 +278,20 @@ def main():
     from nn.model import VGGParams, synthetic_weights
     params = VGGParams(synthetic_weights('16', 0), '16', None, dev)
     S = args.scale
-    eng, rng = build_engine(params, S, dev, seed=rank)
-    idx = index_stream(S, max(8, min(64, args.steps + args.warmup)), rng, dev)
+    strips = None
+    if args.mode == "strips" and world > 1:
+        from nn import parallel as par
+        strips = par.strip_plan(S, world, rank)
+        if strips is None:
+            raise SystemExit(f"--mode strips: sharding a {S}-row image over {world} ranks does not pay (see strip_plan)")
+    eng, rng = build_engine(params, S, dev, seed=0 if strips else rank, strips=strips)
+    count = max(8, min(64, args.steps + args.warmup))
+    if strips is not None:
+        idx, offsets = strip_index_stream(S, count, rng, dev, strips)
+        global run_steps
+        run_steps = lambda e, ix, first, n: [e.step([ix[i % ix.shape[0]]], offsets[i % ix.shape[0]]) for i in range(first, first + n)]
+    else:
+        idx = index_stream(S, count, rng, dev)
     if not args.no_graph:
         eng.capture_graph([idx[0]])
 
@@ -280,6 +308,8 @@ def main():
     torch.cuda.synchronize()
     from nn import parallel
     value, elapsed = parallel.aggregate_throughput(args.steps, time.perf_counter() - t0, device=dev)
+    if strips is not None:
+        value /= world                    # ONE job: its steps are not multiplied by the ranks
     losses = eng.losses()
 
     out = None
@@ -287,40 +317,43 @@ def main():
         n_gpus = world
         out = {"metric": "optimisation_steps_per_sec_1024px_pair", "value": round(value, 3), "unit": "steps/s",
                "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strips is not None else "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{S}px content/style pair, {S}x{S} scale of the coarse-to-fine pyramid, "
                                       f"{SAMPLES} samples x D={D}, VGG16 (seeded He-normal weights), "
                                       f"RMSprop pixel update", "scale_px": S, "samples": SAMPLES,
-                          "parallelism": "replicas (one pair per GPU)" if n_gpus > 1 else "single GPU"},
-               "loss_after": round(losses["loss"], 5), "launch_mode": "eager" if args.no_graph else "hipGraph"}
-        # ---- per-kernel-family HIP-event timing (separate, untimed pass)
-        eng._graph = None                         # per-launch events need eager launches
-        fam = time_kernel_families(eng, idx, 3)
-        conv_names = [n for n in ("conv3x3_relu_fwd", "conv3x3_dgrad", "conv3x3_winograd_fwd", "conv3x3_winograd_dgrad")
-                      if n in fam]
-        conv_ms = sum(fam[n]["ms_per_step"] for n in conv_names)
-        conv_launches = sum(fam[n]["launches_per_step"] for n in conv_names)
-        c3 = 2.0 * 9 * 3 * 64 * S * S
-        algo = 2.0 * (conv_flops(params, S, S) - c3)       # direct-form FLOP of the 12 MFMA conv layers, fwd + dgrad
-        macs_per_out = {0: 9.0, 2: 4.0, 4: 2.25}          # direct, F(2x2,3x3), F(4x4,3x3)
-        executed = 2.0 * sum(2.0 * macs_per_out[t] * L["cin"] * L["cout"] * a.shape[1] * a.shape[2]
-                             for L, a, t in zip(params.layers, eng.trunk.acts, eng.trunk.wtile) if L["cin"] != 3)
-        tf = algo / (conv_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA: gemm_kc_pipe_kernel (batched Winograd-domain GEMMs: F(4x4,3x3) from "
-                                     "32x32 px up, F(2x2,3x3) below for Cin>=128) incl. winograd*_in/out_kernel, and "
-                                     "conv3x3_mfma_pipe_kernel (direct implicit GEMM, small Cin=64 layers); fwd + dgrad, all launches of a step",
-                           "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
-                           "traffic_unit": "HBM bytes per conv launch, PMC FETCH_SIZE x2 + WRITE_SIZE "
-                                           "(profiles/r01_hbm_traffic_by_kernel.csv)",
-                           "algorithmic_gflop_per_step": round(algo / 1e9, 1),
-                           "mfma_executed_gflop_per_step": round(executed / 1e9, 1),
-                           "mfma_executed_tflops": round(executed / (conv_ms * 1e-3) / 1e12, 2),
-                           "launches_per_step": conv_launches,
-                           "avg_launch_ms": round(conv_ms / conv_launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
-        out["roofline_pairwise"] = pairwise_roofline(dev)
-        out["kernel_families_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(fam.items())}
+                          "parallelism": ("one pair sharded by image strips (halo recompute), 2 all-reduces per step"
+                                          if strips is not None else
+                                          "replicas (one pair per GPU)" if n_gpus > 1 else "single GPU")},
+               "loss_after": round(losses["loss"], 5), "launch_mode": "eager" if (args.no_graph or strips is not None) else "hipGraph"}
+        if strips is None:              # (the sharded step needs every rank: no rank-0-only pass)
+            # ---- per-kernel-family HIP-event timing (separate, untimed pass)
+            eng._graph = None                         # per-launch events need eager launches
+            fam = time_kernel_families(eng, idx, 3)
+            conv_names = [n for n in ("conv3x3_relu_fwd", "conv3x3_dgrad", "conv3x3_winograd_fwd", "conv3x3_winograd_dgrad")
+                          if n in fam]
+            conv_ms = sum(fam[n]["ms_per_step"] for n in conv_names)
+            conv_launches = sum(fam[n]["launches_per_step"] for n in conv_names)
+            c3 = 2.0 * 9 * 3 * 64 * S * S
+            algo = 2.0 * (conv_flops(params, S, S) - c3)       # direct-form FLOP of the 12 MFMA conv layers, fwd + dgrad
+            macs_per_out = {0: 9.0, 2: 4.0, 4: 2.25}          # direct, F(2x2,3x3), F(4x4,3x3)
+            executed = 2.0 * sum(2.0 * macs_per_out[t] * L["cin"] * L["cout"] * a.shape[1] * a.shape[2]
+                                 for L, a, t in zip(params.layers, eng.trunk.acts, eng.trunk.wtile) if L["cin"] != 3)
+            tf = algo / (conv_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA, Winograd F(4x4,3x3): winograd43_fused_kernel (transforms + 36 GEMMs "
+                                         "on chip; layers up to 256 output channels) and winograd43_in_kernel -> gemm_kc_pipe_kernel x36 "
+                                         "-> winograd43_out_kernel (512-channel layers); fwd + dgrad, all conv launches of a step",
+                               "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                               "traffic_unit": "HBM bytes per conv launch, PMC FETCH_SIZE x2 + WRITE_SIZE "
+                                               "(profiles/r01_hbm_traffic_by_kernel.csv)",
+                               "algorithmic_gflop_per_step": round(algo / 1e9, 1),
+                               "mfma_executed_gflop_per_step": round(executed / 1e9, 1),
+                               "mfma_executed_tflops": round(executed / (conv_ms * 1e-3) / 1e12, 2),
+                               "launches_per_step": conv_launches,
+                               "avg_launch_ms": round(conv_ms / conv_launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
+            out["roofline_pairwise"] = pairwise_roofline(dev)
+            out["kernel_families_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(fam.items())}
     if rank == 0 and not args.no_pyramid and world == 1:
         del eng
         torch.cuda.empty_cache()

@@ -117,6 +117,10 @@ typedef struct {
   float div[STROTSS_MAX_DIVS];                    /* cumulative `indices /= y` chain (float32) */
   const float* map[STROTSS_MAX_MAPS];             /* gather: sources; scatter: activations   */
   float* gmap[STROTSS_MAX_MAPS];                  /* scatter only: gradient buffers           */
+  /* Row window (spatially sharded trunk): when rows[k] > 0 the buffers of map k hold only rows
+   * [row0[k], row0[k] + rows[k]) of a map whose full height is h[k]; coordinates and clipping stay those of
+   * the full map (strotss_utils.py:43-64), the taps are then shifted into the window.  rows[k] == 0: whole map. */
+  int row0[STROTSS_MAX_MAPS], rows[STROTSS_MAX_MAPS];
 } strotss_maps_t;
 /* out(rows, ld): row s < n = concat_k sample(map_k, idx[s]); bilinear != 0 -> 4-tap weights of
  * strotss_utils.py:43-70, else truncating nearest (72-75).  idx: (n,2) float32 (row, col). */

@@ -94,11 +94,18 @@ __device__ __forceinline__ SampleTap sample_tap(const strotss_maps_t& m, int k, 
     t.wd = dx * dy;
     const int x0 = (int)fminf(fmaxf(gxf, 0.f), (float)(h - 1));
     const int y0 = (int)fminf(fmaxf(gyf, 0.f), (float)(w - 1));
-    const int x1 = min(x0 + 1, h - 1), y1 = min(y0 + 1, w - 1);
-    t.ia = x0 * w + y0; t.ib = x0 * w + y1; t.ic = x1 * w + y0; t.id = x1 * w + y1;
+    int x1 = min(x0 + 1, h - 1);
+    const int y1 = min(y0 + 1, w - 1);
+    int xa = x0;
+    if (m.rows[k] > 0) {                            // window of a sharded map (clamped: never out of the buffer)
+      xa = min(max(x0 - m.row0[k], 0), m.rows[k] - 1);
+      x1 = min(max(x1 - m.row0[k], 0), m.rows[k] - 1);
+    }
+    t.ia = xa * w + y0; t.ib = xa * w + y1; t.ic = x1 * w + y0; t.id = x1 * w + y1;
   } else {
-    const int xi = (int)fminf(fmaxf(gx, 0.f), (float)(h - 1));   // clip, then truncating cast
+    int xi = (int)fminf(fmaxf(gx, 0.f), (float)(h - 1));   // clip, then truncating cast
     const int yi = (int)fminf(fmaxf(gy, 0.f), (float)(w - 1));
+    if (m.rows[k] > 0) xi = min(max(xi - m.row0[k], 0), m.rows[k] - 1);
     t.ia = t.ib = t.ic = t.id = xi * w + yi;
     t.wa = 1.f; t.wb = t.wc = t.wd = 0.f;
   }
@@ -214,6 +221,7 @@ int maps_ok(const strotss_maps_t* m) {
   for (int k = 0; k < m->n_maps; ++k) {
     if (m->h[k] <= 0 || m->w[k] <= 0 || m->c[k] <= 0 || !m->map[k]) return 0;
     if (m->n_div[k] < 0 || m->n_div[k] > STROTSS_MAX_DIVS) return 0;
+    if (m->rows[k] < 0 || m->row0[k] < 0 || m->row0[k] + m->rows[k] > m->h[k]) return 0;
   }
   return 1;
 }

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Sequence
+from typing import Tuple, Optional, Sequence
 
 import torch
 
@@ -29,7 +29,8 @@ class MapsT(C.Structure):
                 ("n_div", C.c_int * MAX_MAPS),
                 ("div", C.c_float * MAX_DIVS),
                 ("map", C.c_void_p * MAX_MAPS),
-                ("gmap", C.c_void_p * MAX_MAPS)]
+                ("gmap", C.c_void_p * MAX_MAPS),
+                ("row0", C.c_int * MAX_MAPS), ("rows", C.c_int * MAX_MAPS)]
 
 
 class TensorsT(C.Structure):
@@ -124,9 +125,12 @@ def require(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
 
 
 def make_maps(maps: Sequence[torch.Tensor], divs_per_map: Sequence[Sequence[float]],
-              gmaps: Optional[Sequence[torch.Tensor]] = None) -> MapsT:
+              gmaps: Optional[Sequence[torch.Tensor]] = None,
+              windows: Optional[Sequence[Tuple[int, int]]] = None) -> MapsT:
     """maps: list of (1,h,w,c) or (h,w,c) tensors; divs_per_map[k]: the divisor chain for map k
-    (each chain is a prefix of the longest one, as the reference's cumulative `indices /= y`)."""
+    (each chain is a prefix of the longest one, as the reference's cumulative `indices /= y`).
+    windows[k] = (row0, full_height): map k holds rows [row0, row0 + its height) of a map that is
+    `full_height` tall (spatially sharded trunk); None: whole maps."""
     if len(maps) > MAX_MAPS:
         raise StrotssHipError("too many maps")
     m = MapsT()
@@ -140,6 +144,10 @@ def make_maps(maps: Sequence[torch.Tensor], divs_per_map: Sequence[Sequence[floa
         require(t, f"map {k}")
         h, w, c = t.shape[-3], t.shape[-2], t.shape[-1]
         m.h[k], m.w[k], m.c[k] = h, w, c
+        if windows is not None and windows[k] is not None:
+            row0, full_h = windows[k]
+            assert 0 <= row0 and row0 + h <= full_h
+            m.h[k], m.row0[k], m.rows[k] = full_h, row0, h
         chain = list(divs_per_map[k])
         assert chain == list(longest[:len(chain)])
         m.n_div[k] = len(chain)

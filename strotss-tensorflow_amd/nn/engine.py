@@ -60,7 +60,7 @@ class StepEngine:
     def __init__(self, params: VGGParams, content_feat: Sequence[torch.Tensor],
                  style_targets: Sequence[StyleTarget], stylized: torch.Tensor, alpha: float,
                  loss_denom: float, lr: float, sample_size: int = 1024, levels: int = 5,
-                 dist_group=None, rho: float = 0.99, eps: float = 1e-8):
+                 dist_group=None, rho: float = 0.99, eps: float = 1e-8, strips: Optional["parallel.StripPlan"] = None):
         dev = stylized.device
         self.params = params
         self.alpha, self.loss_denom, self.lr, self.rho, self.eps = float(alpha), float(loss_denom), float(lr), rho, eps
@@ -77,7 +77,12 @@ class StepEngine:
         self.sizes = [(int(v.shape[1]), int(v.shape[2])) for v in self.variables]
         # fold temporaries: f[k] = v[k] + up(f[k+1]); f[0] is the image
         self.fold = [torch.empty_like(v) for v in self.variables[:-1]]
-        self.trunk = VGGTrunk(params, h, w, with_grad=True)
+        # image strips (nn/parallel.py): the trunk covers rows [win0, win1) only; everything else is full-size
+        self.strips = strips
+        win0, win1 = (strips.win0, strips.win1) if strips is not None else (0, h)
+        if strips is not None:
+            assert self.R == 1 and strips.h == h, "image strips: one region, plan made for this scale"
+        self.trunk = VGGTrunk(params, win1 - win0, w, with_grad=True)
         self.d = 3 + sum(int(a.shape[-1]) for a in (self.trunk.acts[i] for i in self.trunk.taps))
         self.ld = _ops.pad32(self.d)
         rows = _ops.pad32(sample_size)
@@ -87,13 +92,29 @@ class StepEngine:
         self.gp = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
         self.scalars = torch.zeros((self.R, 8), dtype=torch.float32, device=dev)
         # gradient of the variables: level 0 aliases the pixel gradient
-        self.gvars = [self.trunk.gimg] + [torch.empty_like(v) for v in self.variables[1:]]
+        if strips is not None:
+            # full-size pixel gradient, zero outside the window; the trunk writes its window rows in place
+            self.gimg_full = torch.zeros((1, h, w, 3), dtype=torch.float32, device=dev)
+            self.trunk.gimg = self.gimg_full[:, win0:win1]
+            assert self.trunk.gimg.is_contiguous()
+            self.gvars = [self.gimg_full] + [torch.empty_like(v) for v in self.variables[1:]]
+        else:
+            self.gvars = [self.trunk.gimg] + [torch.empty_like(v) for v in self.variables[1:]]
         # hypercolumn descriptors (pointers are static for the life of the engine)
-        self.pred_maps = [self.fold[0]] + [self.trunk.acts[i] for i in self.trunk.taps]
+        self._img_window = self.fold[0][:, win0:win1]
+        self.pred_maps = [self._img_window] + [self.trunk.acts[i] for i in self.trunk.taps]
         gmaps = [self.trunk.gimg] + [self.trunk.grads[i] for i in self.trunk.taps]
-        shapes = [_ops.hwc(m)[:2] for m in self.pred_maps]
+        # divisors and clipping are those of the FULL maps (content_feat holds them), also for a window
+        shapes = [_ops.hwc(m)[:2] for m in self.content_feat]
         self.divs = _ops.map_divisors(shapes)
-        self._mt_pred = _hip.make_maps(self.pred_maps, self.divs, gmaps)
+        windows = None
+        if strips is not None:
+            windows = []
+            for k, (m, (fh, _)) in enumerate(zip(self.pred_maps, shapes)):
+                shift = (h // fh).bit_length() - 1 if fh < h else 0      # number of 2x2 pools above map k
+                assert win0 % (1 << shift) == 0 and (win0 >> shift) + int(m.shape[1]) <= fh
+                windows.append((win0 >> shift, fh))
+        self._mt_pred = _hip.make_maps(self.pred_maps, self.divs, gmaps, windows)
         self._mt_content = _hip.make_maps(self.content_feat, self.divs)
         self._layer_to_map = {li: k + 1 for k, li in enumerate(self.trunk.taps)}
         self._layer_to_map[-1] = 0
@@ -101,6 +122,8 @@ class StepEngine:
         self.group = dist_group
         self.rank, self.world = parallel.world_info(dist_group) if dist_group is not None else (0, 1)
         self.my_regions = parallel.regions_for_rank(self.R, self.rank, self.world)
+        if strips is not None:            # strips shard the image, not the regions: every rank runs region 0
+            self.my_regions, self.world = [0], 1
         self._idx: List[Optional[torch.Tensor]] = [None] * self.R
         self.steps_done = 0
         self._graph = None
@@ -138,13 +161,24 @@ class StepEngine:
     def _scatter(self, layer_index: int):
         k = self._layer_to_map[layer_index]
         for r in self.my_regions:
-            idx = self._idx[r]
-            _ops.hypercol_scatter(self.pred_maps, None, idx, self.gp[r], relu_mask_from=1, map_begin=k,
+            idx, gp = self._idx[r], self.gp[r]
+            if self.strips is not None:           # this rank's block of samples only
+                idx, gp = idx[self._o0:self._o1], gp[self._o0:self._o1]
+            _ops.hypercol_scatter(self.pred_maps, None, idx, gp, relu_mask_from=1, map_begin=k,
                                   map_end=k + 1, maps_t=self._mt_pred)
 
-    def forward_backward(self, indices: Sequence[torch.Tensor]) -> None:
-        """train_step (run_strotss.py:131-142 / 104-125): fills self.gvars and self.scalars."""
+    def forward_backward(self, indices: Sequence[torch.Tensor], strip_offsets: Optional[Sequence[int]] = None) -> None:
+        """train_step (run_strotss.py:131-142 / 104-125): fills self.gvars and self.scalars.
+        With image strips `indices[0]` must be ordered by owning rank and `strip_offsets` be the world + 1 block
+        offsets (parallel.sort_indices_by_strip)."""
         assert len(indices) == self.R
+        if self.strips is not None:
+            self._strip_stage_a(indices[0], strip_offsets)
+            parallel.allreduce_sum_(self.pf[0], self.group)       # rows of the other ranks' samples arrive here
+            self._strip_stage_b()
+            parallel.allreduce_sum_(self.gimg_full, self.group)   # windows overlap by the margins: sum
+            self._fold_adjoint()
+            return
         if self.world > 1:
             self.scalars.zero_()          # regions owned by other ranks arrive through the all-reduce
         img = self.fold_forward()
@@ -164,16 +198,54 @@ class StepEngine:
         if self.world > 1:
             parallel.allreduce_sum_(gimg, self.group)          # one RCCL all-reduce on the pixel gradient
             parallel.allreduce_sum_(self.scalars, self.group)   # (tiny) so every rank can log
-        # adjoint of the fold: gvars[k] = up^T(gvars[k-1])
+        self._fold_adjoint()
+
+    def _fold_adjoint(self) -> None:
+        """gvars[k] = up^T(gvars[k-1]): adjoint of the fold"""
         for k in range(1, len(self.variables)):
             hk, wk = self.sizes[k]
             _ops.resize_bilinear_adjoint(self.gvars[k - 1], hk, wk, out=self.gvars[k])
+
+    # ---- image strips: the step in three stages with an all-reduce between them
+    def _strip_stage_a(self, idx: torch.Tensor, offsets: Sequence[int]) -> None:
+        """fold (replicated), trunk forward on the window, content rows (all, from the replicated full maps),
+        prediction rows of THIS rank's samples (the others stay zero for the all-reduce)."""
+        idx = _hip.require(idx, "indices")
+        n = int(idx.shape[0])
+        assert offsets is not None and len(offsets) == self.strips.world + 1 and offsets[-1] == n
+        assert 0 < n <= self.sample_size and idx.shape[1] == 2
+        self._idx[0], self._n = idx, n
+        self._o0, self._o1 = int(offsets[self.strips.rank]), int(offsets[self.strips.rank + 1])
+        self.fold_forward()
+        self.trunk.forward(self._img_window)
+        self._gather(self._mt_content, idx, self.cf[0])
+        self.pf[0].zero_()
+        if self._o1 > self._o0:
+            _hip.check(_hip.lib().strotss_hypercol_gather(
+                _hip.C.byref(self._mt_pred), idx[self._o0:].data_ptr(), self._o1 - self._o0, 1,
+                self.pf[0][self._o0:].data_ptr(), self.ld, _hip.stream_ptr()), "hypercol_gather")
+
+    def _strip_stage_b(self) -> None:
+        """losses on the assembled features (replicated), backward of this rank's rows through its window."""
+        self._losses(0, self._n)
+        if self._o1 > self._o0:
+            self.trunk.backward(self._scatter)
+        else:
+            self.trunk.gimg.zero_()
+        # rows outside the window still hold the previous step's all-reduced sum
+        self.gimg_full[:, :self.strips.win0].zero_()
+        self.gimg_full[:, self.strips.win1:].zero_()
 
     def apply_gradients(self) -> None:
         """opt.apply_gradients (run_strotss.py:148): Keras RMSprop, all 6 tensors in one launch."""
         _ops.rmsprop_step(self.variables, self.rms, self.gvars, self.lr, self.rho, self.eps)
 
-    def step(self, indices: Sequence[torch.Tensor]) -> None:
+    def step(self, indices: Sequence[torch.Tensor], strip_offsets: Optional[Sequence[int]] = None) -> None:
+        if self.strips is not None:
+            self.forward_backward(indices, strip_offsets)
+            self.apply_gradients()
+            self.steps_done += 1
+            return
         if self._graph is not None and all(int(i.shape[0]) == self._graph_n[r] for r, i in enumerate(indices)):
             for dst, src in zip(self._graph_idx, indices):
                 dst.copy_(src, non_blocking=True)
@@ -189,7 +261,7 @@ class StepEngine:
         sets are copied into static buffers before each replay; a step whose index counts differ from
         the captured ones runs eagerly.  The captured step does not advance the optimisation: the
         variables / RMSprop slots are snapshotted around the warm-up and capture passes."""
-        if self.world > 1:
+        if self.world > 1 or self.strips is not None:
             return                      # collectives stay outside graphs in this build
         snap = [t.clone() for t in self.variables + self.rms]
         self._graph_idx = [i.clone() for i in example_indices]

@@ -11,12 +11,24 @@ The reference is single-device (nn/utils.py:73-85 picks ONE GPU; no tf.distribut
     the fold adjoint, so all ranks apply the identical RMSprop update.  The six pyramid-variable
     gradients are not reduced separately: the fold adjoint is linear.
 
+  * image strips (one image faster on several GPUs): the trunk is ~90 % of a step, so rank r runs
+    it only on rows [own0 - margin, own1 + margin) of the image, `margin` >= the receptive-field radius of the
+    deepest tap (halo RECOMPUTE, no per-layer exchange: the trunk kernels are used unchanged on the sub-image).
+    A sample belongs to the rank owning its image row; samples are ordered by owner so each rank gathers a
+    contiguous block of feature rows, ONE all-reduce(sum) over zero-filled rows assembles the (N, D) matrix, the
+    losses run replicated (bitwise identical on every rank), each rank scatters and back-propagates its own rows
+    through its window, and ONE all-reduce(sum) of the pixel gradient (zero outside the window) precedes the
+    replicated fold adjoint + RMSprop.  Exact up to fp32 rounding of the Winograd tile alignment.
+
 Only this file touches torch.distributed; it has no GPU dependency, so the sharding logic is
 covered by world_size-2 gloo tests on CPU (tests/test_parallel_gloo.py).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
 
 import torch
 
@@ -61,3 +73,53 @@ def aggregate_throughput(units_per_rank: float, elapsed_local: float, group=None
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     elapsed = float(t.item())
     return world * units_per_rank / elapsed, elapsed
+
+
+# ------------------------------------------------------------------ image strips
+STRIP_MARGIN = 128        # halo rows per side; receptive-field radius of block5_conv3 in image pixels is < 110
+STRIP_ALIGN = 16          # four 2x2 pools: windows start on multiples of 16 so every pooled grid stays aligned
+
+
+@dataclass(frozen=True)
+class StripPlan:
+    """Rows of an `h`-row image for rank `rank` of `world`: it owns [own0, own1) (the samples whose image row lies
+    there) and runs the trunk on the window [win0, win1) = own +- margin, clipped to the image."""
+    h: int
+    world: int
+    rank: int
+    bounds: Tuple[int, ...]          # world + 1 strip boundaries, bounds[0] = 0, bounds[-1] = h
+    win0: int
+    win1: int
+
+    @property
+    def own0(self) -> int:
+        return self.bounds[self.rank]
+
+    @property
+    def own1(self) -> int:
+        return self.bounds[self.rank + 1]
+
+
+def strip_plan(h: int, world: int, rank: int, margin: int = STRIP_MARGIN, align: int = STRIP_ALIGN) -> Optional[StripPlan]:
+    """None when sharding does not pay: one rank, an empty strip, or windows that cover (almost) the whole image."""
+    if world <= 1:
+        return None
+    assert margin % align == 0
+    bounds = [0] + [min(h, (r * h // world + align - 1) // align * align) for r in range(1, world)] + [h]
+    if any(b1 <= b0 for b0, b1 in zip(bounds, bounds[1:])):
+        return None
+    win0, win1 = max(0, bounds[rank] - margin), min(h, bounds[rank + 1] + margin)
+    widest = max(min(h, bounds[r + 1] + margin) - max(0, bounds[r] - margin) for r in range(world))
+    if widest * 4 > h * 3:            # less than 25 % of the trunk saved: replicate instead
+        return None
+    return StripPlan(h, world, rank, tuple(bounds), win0, win1)
+
+
+def sort_indices_by_strip(idx: np.ndarray, plan: StripPlan) -> Tuple[np.ndarray, List[int]]:
+    """idx: (n, 2) float32 (row, col) sample coordinates.  Returns them stably ordered by owning rank and the
+    world + 1 row offsets of the ranks' blocks.  The losses are invariant to the sample order as long as the content
+    and prediction features use the same one."""
+    owner = np.searchsorted(np.asarray(plan.bounds[1:-1]), idx[:, 0], side="right")
+    order = np.argsort(owner, kind="stable")
+    counts = np.bincount(owner, minlength=plan.world)
+    return np.ascontiguousarray(idx[order]), [0] + np.cumsum(counts).tolist()

@@ -11,9 +11,13 @@ Every reference flag is kept (run_strotss.py:165-178 there).  Additions:
   --log_every N     read the three scalars back every N steps (the reference formats them every step,
                     i.e. one device->host sync per step; default 10, 1 restores that)
   --no_graph        launch kernels one by one instead of replaying one hipGraph per step
+  --strips          under torchrun (one process per GPU): ONE image on all GPUs -- every rank runs the trunk on its strip
+                    of the image (+ halo) at the scales where that pays, two all-reduces per step (nn/parallel.py);
+                    rank 0 writes the output
 `--level` is coerced to int (the reference declares type=float, which breaks `range(args.level)`).
 """
 import argparse
+import os
 
 import torch
 
@@ -86,18 +90,22 @@ def _style_targets(params, style, style_masks, sampling):
     return targets
 
 
-def _optimise_scale(eng, scl: int, content_masks, args, dev):
+def _optimise_scale(eng, scl: int, content_masks, args, dev, quiet: bool = False):
     """`max_iter` RMSprop steps; fresh sample coordinates every step (they are drawn inside the reference's
     traced train_step as well)."""
+    from nn import parallel
     masks_here = [None if m is None else strotss.mask_at_scale(m, eng.h, eng.w) for m in content_masks]
     log_every = max(1, int(getattr(args, "log_every", 10)))
-    with tqdm(range(args.max_iter)) as bar:
+    with tqdm(range(args.max_iter), disable=quiet) as bar:
         for it in bar:
-            idx = [torch.from_numpy(strotss.make_indices_np(eng.h, eng.w, True, SAMPLE_SIZE, rand.index_rng, mk)).to(dev)
-                   for mk in masks_here]
+            idx_np = [strotss.make_indices_np(eng.h, eng.w, True, SAMPLE_SIZE, rand.index_rng, mk) for mk in masks_here]
+            offsets = None
+            if eng.strips is not None:            # same seed on every rank: identical draws, ordered by owner
+                idx_np[0], offsets = parallel.sort_indices_by_strip(idx_np[0], eng.strips)
+            idx = [torch.from_numpy(i).to(dev) for i in idx_np]
             if it == 0 and not getattr(args, "no_graph", False):
                 eng.capture_graph(idx)
-            eng.step(idx)
+            eng.step(idx, offsets)
             if (it + 1) % log_every == 0 or it + 1 == args.max_iter:
                 r = eng.losses()
                 bar.set_description(f"Scale: {scl:4d} - It: {it+1:4d}")
@@ -110,6 +118,15 @@ def run(args: argparse.Namespace):
 
     seed = int(getattr(args, "seed", 0))
     rand.seed_everything(seed)
+    from nn import parallel
+    rank, world = 0, 1
+    if getattr(args, "strips", False) and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+            dist.init_process_group(os.environ.get("STROTSS_DIST_BACKEND", "nccl"))
+        rank, world = dist.get_rank(), dist.get_world_size()
     dev = utils.device()
     level, first = int(args.level), int(getattr(args, "start_level", 0))
 
@@ -127,11 +144,12 @@ def run(args: argparse.Namespace):
         scl_content, scl_style = utils.resize(content, scl), utils.resize(style, scl)
         stylized, lr = _initial_image(position, position > 0 and i == level - 1, stylized, scl_content, scl_style,
                                       args.lr)
+        plan = parallel.strip_plan(int(scl_content.shape[1]), world, rank) if world > 1 and style_masks == [None] else None
         eng = strotss_engine.StepEngine(
             vgg.params, strotss_engine.extract_features(vgg.params, scl_content),
             _style_targets(vgg.params, scl_style, style_masks, sampling), stylized, alpha,
-            loss_denom=2. + alpha + 1. / max(alpha, 1.), lr=lr, sample_size=SAMPLE_SIZE)
-        _optimise_scale(eng, scl, content_masks, args, dev)
+            loss_denom=2. + alpha + 1. / max(alpha, 1.), lr=lr, sample_size=SAMPLE_SIZE, strips=plan)
+        _optimise_scale(eng, scl, content_masks, args, dev, quiet=rank != 0)
         stylized = eng.stylized()
         del eng
         alpha /= 2.
@@ -140,8 +158,9 @@ def run(args: argparse.Namespace):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     timer.stop()
-    utils.logger.info(f"Done in {timer.elapsed_time:.2f}s.")
-    utils.write_image(final, args.output_path)
+    if rank == 0:
+        utils.logger.info(f"Done in {timer.elapsed_time:.2f}s.")
+        utils.write_image(final, args.output_path)
     return final
 
 
@@ -156,6 +175,7 @@ _FLAGS = (
     (("--start_level",), dict(type=int, default=0)), (("--seed",), dict(type=int, default=0)),
     (("--weights",), dict(type=str, default=None)), (("--log_every",), dict(type=int, default=10)),
     (("--no_graph",), dict(action='store_true', help="eager kernel launches instead of one hipGraph per step")),
+    (("--strips",), dict(action='store_true', help="under torchrun: shard ONE image over the GPUs by image strips")),
 )
 
 

@@ -1,0 +1,144 @@
+"""GPU: image strips (nn/parallel.py).  The ranks of a sharded step are emulated one after the
+other on the single GPU of the test box, with the two all-reduces done by hand between the stages; the result must
+equal the unsharded engine's step on the same inputs (exact construction: halo recompute with a margin above the
+receptive-field radius; only fp32 rounding from the Winograd tile alignment differs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _img(h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(1, h, w, 3, generator=g, dtype=torch.float32)
+    return torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1).contiguous()
+
+
+def _engines(h, w, world, n_samples, margin):
+    from nn import _ops, engine, parallel, strotss_utils as SU
+    from nn.model import VGGParams, synthetic_weights
+    params = VGGParams(synthetic_weights('16', 0), '16', None, DEV)
+    content, style = _img(h, w, 1).to(DEV), _img(h // 2, w, 2).to(DEV)
+    cfeat = engine.extract_features(params, content)
+    sfeat = engine.extract_features(params, style)
+    rng = np.random.default_rng(0)
+    s_idx = torch.from_numpy(SU.make_indices_np(h // 2, w, False, n_samples, rng)).to(DEV)
+    target = engine.StyleTarget.build(_ops.hypercol_gather(sfeat, s_idx, False), int(s_idx.shape[0]), 2179)
+    init = SU.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
+    alpha = 4.0
+    mk = lambda plan: engine.StepEngine(params, cfeat, [target], init, alpha, 2.0 + alpha + 1.0 / alpha, 2e-3,
+                                        sample_size=n_samples, strips=plan)
+    plans = [parallel.strip_plan(h, world, r, margin=margin) for r in range(world)]
+    assert all(p is not None for p in plans)
+    idx = SU.make_indices_np(h, w, True, n_samples, rng)
+    return mk(None), [mk(p) for p in plans], plans, idx
+
+
+@pytest.mark.parametrize("cfg", [(512, 96, 2, 128), (640, 64, 3, 128), (601, 72, 2, 128)])
+def test_strip_sharded_step_equals_unsharded(cfg):
+    from nn import parallel
+    h, w, world, margin = cfg
+    ref, engs, plans, idx = _engines(h, w, world, 256, margin)
+    idx_sorted, offs = parallel.sort_indices_by_strip(idx, plans[0])
+    assert offs[-1] == idx.shape[0] and all(o1 > o0 for o0, o1 in zip(offs, offs[1:])), "every strip holds samples"
+    ti = torch.from_numpy(idx_sorted).to(DEV)
+    ref.forward_backward([ti])
+    for e in engs:
+        e._strip_stage_a(ti, offs)
+    pf = sum(e.pf[0] for e in engs)
+    # the gathered rows: disjoint blocks, equal to the unsharded gather up to the conv rounding
+    assert float((pf - ref.pf[0]).abs().max()) < 2e-4 * float(ref.pf[0].abs().max())
+    for e in engs:
+        e.pf[0].copy_(pf)
+        e._strip_stage_b()
+    g = sum(e.gimg_full for e in engs)
+    for e in engs:
+        e.gimg_full.copy_(g)
+        e._fold_adjoint()
+    torch.cuda.synchronize()
+    la, lb = ref.losses(), engs[0].losses()
+    for k in ("loss", "loss_c", "loss_s"):
+        assert abs(la[k] - lb[k]) < 2e-5 * max(1.0, abs(la[k])), (k, la, lb)
+    assert engs[0].losses() == engs[-1].losses()          # replicated loss section: bitwise identical
+    for a, b in zip(ref.gvars, engs[0].gvars):
+        rel = float((a - b).norm() / a.norm())
+        assert rel < 2e-3, rel                            # sign flips of the L1 / hard-min losses on rounding noise
+    # one update on every emulated rank: identical variables everywhere
+    for e in engs:
+        e.apply_gradients()
+    for a, b in zip(engs[0].variables, engs[-1].variables):
+        assert torch.equal(a, b)
+    # a second step from the (all-reduced) state of the first: the pixel gradient must again be the unsharded one
+    ref.apply_gradients()
+    for e in engs:                                  # put every engine on the reference's variables
+        for v, r_, a, b in zip(e.variables, e.rms, ref.variables, ref.rms):
+            v.copy_(a); r_.copy_(b)
+    ref.forward_backward([ti])
+    for e in engs:
+        e._strip_stage_a(ti, offs)
+    pf = sum(e.pf[0] for e in engs)
+    for e in engs:
+        e.pf[0].copy_(pf)
+        e._strip_stage_b()
+    g = sum(e.gimg_full for e in engs)
+    rel = float((g - ref.gvars[0]).norm() / ref.gvars[0].norm())
+    assert rel < 2e-3, rel
+
+
+def test_strip_margin_must_cover_the_receptive_field():
+    """With a margin far below the receptive-field radius the halo is wrong and the test above would fail:
+    guards against the margin constant being silently reduced."""
+    from nn import parallel
+    h, w, world = 512, 64, 2
+    ref, engs, plans, idx = _engines(h, w, world, 256, 16)
+    idx_sorted, offs = parallel.sort_indices_by_strip(idx, plans[0])
+    ti = torch.from_numpy(idx_sorted).to(DEV)
+    ref.forward_backward([ti])
+    for e in engs:
+        e._strip_stage_a(ti, offs)
+    pf = sum(e.pf[0] for e in engs)
+    assert float((pf - ref.pf[0]).abs().max()) > 1e-3 * float(ref.pf[0].abs().max())
+    assert parallel.STRIP_MARGIN >= 112 and parallel.STRIP_MARGIN % parallel.STRIP_ALIGN == 0
+
+
+def test_cli_strips_two_ranks_on_one_gpu(tmp_path):
+    """The real sharded path with real collectives: two processes (both on this box's single GPU, gloo instead of
+    RCCL, which refuses two ranks on one device) run `run_strotss.py --strips` on the 512-px scale; their output must
+    match the single-process run of the same command up to the rounding noise RMSprop's sign-like first steps amplify."""
+    import os, subprocess, sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "strotss-tensorflow_amd")
+    rng = np.random.default_rng(0)
+    for name, (h, w) in (("c.jpg", (512, 160)), ("s.jpg", (300, 200))):
+        arr = (rng.random((h // 16, w // 16, 3)) * 255).astype(np.uint8)
+        Image.fromarray(arr).resize((w, h), Image.BILINEAR).save(tmp_path / name, quality=95)
+    base = [sys.executable, os.path.join(pkg, "run_strotss.py"), str(tmp_path / "c.jpg"), str(tmp_path / "s.jpg"),
+            "--start_level", "3", "--level", "4", "--max_iter", "2", "--log_every", "1"]
+    env = dict(os.environ, PYTHONPATH=pkg + os.pathsep + root)
+    one = subprocess.run(base + ["-o", str(tmp_path / "one.jpg")], env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+                 STROTSS_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(base + ["--strips", "-o", str(tmp_path / f"two{rank}.jpg")], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert os.path.exists(tmp_path / "two0.jpg") and not os.path.exists(tmp_path / "two1.jpg")   # rank 0 writes
+    a = np.asarray(Image.open(tmp_path / "one.jpg")).astype(np.int32)
+    b = np.asarray(Image.open(tmp_path / "two0.jpg")).astype(np.int32)
+    assert a.shape == b.shape == (512, 160, 3)
+    # postprocess (strotss_utils.py:170-175) rescales by the global min / max, i.e. by two single pixels: compare up
+    # to that affine map (the step losses printed by both runs agree to all shown digits)
+    A = np.stack([b.ravel(), np.ones(b.size)], 1).astype(np.float64)
+    coef, *_ = np.linalg.lstsq(A, a.ravel().astype(np.float64), rcond=None)
+    fit = A @ coef
+    assert 0.95 < coef[0] < 1.05 and np.abs(fit - a.ravel()).mean() < 1.5, (coef, np.abs(fit - a.ravel()).mean())
+    import re
+    losses = [re.findall(r"loss=([0-9.]+), loss_c=([0-9.]+), loss_s=([0-9.]+)", t)[-1] for t in (one.stderr, outs[0][1])]
+    assert losses[0] == losses[1], losses

@@ -91,3 +91,28 @@ def test_region_ownership_covers_everything():
         for world in (1, 2, 4, 8):
             owned = sorted(r for k in range(world) for r in parallel.regions_for_rank(R, k, world))
             assert owned == list(range(R))
+
+
+def test_strip_plan_and_sample_ownership():
+    """Host logic of the image strips: aligned boundaries, windows = own +- margin clipped to the image,
+    replication when sharding would not pay, and the owner ordering of the samples."""
+    import numpy as np
+    from nn import parallel as P
+    for h, world in ((1024, 8), (1024, 4), (1024, 2), (683, 2), (512, 4)):
+        plans = [P.strip_plan(h, world, r) for r in range(world)]
+        assert all(p is not None for p in plans)
+        assert plans[0].bounds[0] == 0 and plans[0].bounds[-1] == h
+        for r, p in enumerate(plans):
+            assert p.own0 % P.STRIP_ALIGN == 0 and p.win0 % P.STRIP_ALIGN == 0
+            assert p.win0 == max(0, p.own0 - P.STRIP_MARGIN) and p.win1 == min(h, p.own1 + P.STRIP_MARGIN)
+            assert p.own1 == plans[min(r + 1, world - 1)].own0 or r == world - 1
+    assert P.strip_plan(256, 2, 0) is None and P.strip_plan(1024, 1, 0) is None and P.strip_plan(64, 8, 3) is None
+    plan = P.strip_plan(1024, 4, 2)
+    rng = np.random.default_rng(0)
+    idx = np.stack([rng.integers(0, 1024, 500), rng.integers(0, 1024, 500)], 1).astype(np.float32)
+    s, offs = P.sort_indices_by_strip(idx, plan)
+    assert offs[0] == 0 and offs[-1] == 500 and len(offs) == 5
+    for r in range(4):
+        rows = s[offs[r]:offs[r + 1], 0]
+        assert ((rows >= plan.bounds[r]) & (rows < plan.bounds[r + 1])).all()
+    assert sorted(map(tuple, s.tolist())) == sorted(map(tuple, idx.tolist()))

@@ -161,7 +161,7 @@ def pmc_traffic(path=os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.c
     import csv
     if not os.path.exists(path):
         return None
-    fam = ("winograd", "gemm_kc_pipe_kernel", "conv3x3_mfma_pipe_kernel")
+    fam = ("winograd", "gemm_kc_pipe_kernel", "conv3x3_mfma_pipe_kernel")     # winograd43_fused_kernel: one kernel = one launch
     total, launches = 0.0, 0
     with open(path) as f:
         rd = csv.reader(f)
@@ -170,7 +170,7 @@ def pmc_traffic(path=os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.c
             if not name.startswith(fam) or ("gemm_kc" in name and "EpiScaleStore" not in name):
                 continue
             total += int(n) * (float(r_mb) + float(w_mb)) * 1e6
-            if not name.startswith("winograd"):
+            if not name.startswith("winograd") or name.startswith("winograd43_fused"):
                 launches += int(n)
     return total / launches if launches else None
 

@@ -150,6 +150,17 @@ size_t strotss_selfsim_workspace_bytes(int n);
 int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int d, int ld,
                             float gscale, float* gpred, float* loss_out, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* Sinkhorn-Knopp transport cost between the style rows (ns) and the prediction rows (n) on the cosine cost matrix.
+ * BUILD-DEFINED: the reference's sinkhorn_knopp (losses.py:83-105) is marked untested, is never called and cannot
+ * execute (`tf.ones_like` of a Python tuple); this implements its evident intent:
+ *   M = cosine_distance(style, pred), K = exp(-l M), v_0 = 1,
+ *   n_iter times:  u = (1/ns) / max(K v, 1e-12),  v = (1/n) / max(K^T u, 1e-12),     loss = sum(u * ((K o M) v)),
+ * and gpred += gscale * dloss/dpred, differentiated THROUGH the iterations as autodiff would (checked against a
+ * float64 autograd restatement, oracle/strotss_oracle.py: sinkhorn_knopp).  n_iter <= 64. */
+size_t strotss_sinkhorn_workspace_bytes(int ns, int n, int n_iter);
+int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n, int d,
+                                 int ld, float l, int n_iter, float gscale, float* gpred, float* loss_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 size_t strotss_remd_workspace_bytes(int ns, int n);
 /* loss_out[0] = relaxed_emd(style, pred, 'cosine') (losses.py:69-80); gpred += gscale*dloss/dpred.
  * rs = row_inv_norm(style) (constant per scale). */

@@ -338,6 +338,22 @@ def relaxed_emd(x, y, distance: str = "cosine"):   # losses.py:69-80
     return torch.where(r_x >= r_y, r_x, r_y)
 
 
+def sinkhorn_knopp(x, y, distance: str = "cosine", l: float = 10.0, N_iter: int = 30):
+    """BUILD-DEFINED (no reference behaviour exists: losses.py:83-105 is marked untested, never called, and raises on
+    `tf.ones_like(shape)` of a tuple).  Its evident intent, with the second marginal 1/len(y):
+    K = exp(-l M); u = p / max(K v, 1e-12); v = q / max(K^T u, 1e-12), N_iter times from v = 1; sum(u * ((K*M) v)).
+    Differentiated through the iterations by autograd, as TF would."""
+    M = dist_metrics[distance](x, y)
+    K = torch.exp(-l * M)
+    p, q = 1.0 / x.shape[0], 1.0 / y.shape[0]
+    v = torch.ones(y.shape[0], 1, dtype=M.dtype)
+    u = torch.ones(x.shape[0], 1, dtype=M.dtype)
+    for _ in range(N_iter):
+        u = p / torch.clamp(K @ v, min=1e-12)
+        v = q / torch.clamp(K.t() @ u, min=1e-12)
+    return (u * ((K * M) @ v)).sum()
+
+
 def convert_rgb_to_yuv(x):                      # strotss_utils.py:166-167
     m = torch.tensor(RGB2YUV, dtype=x.dtype)
     return x[:, :3] @ m

@@ -343,11 +343,12 @@ int st_moment_bwd_gemm(const float* cy, int n, int ld, const float* T, float alp
   return launch_pipe<64, 64>(cy, ld, n, 0, T, ld, ld, 0, ld, 1, e, s);
 }
 
-// dX(n x ld) += g * r_i (Mq(n x kpad) @ X(kpad x ld) - xhat q)
-int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, const float* r, const float* q,
-                        int n, int ld, float g, float* dx, hipStream_t s) {
+// dX(n x ld) += g * r_i (Mq(n x kpad) @ B(kpad x ld) - xhat q); B = x for self_similarity, the other side's rows for
+// a cross cost matrix (sinkhorn)
+int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* bmat, const float* x, const float* r,
+                        const float* q, int n, int ld, float g, float* dx, hipStream_t s) {
   EpiSelfsimBwd e{x, r, q, dx, ld, n, ld, g};
-  return launch<64, 64, true, false>(Mq, ldm, n, x, ld, ld, kpad, e, s);
+  return launch<64, 64, true, false>(Mq, ldm, n, bmat, ld, ld, kpad, e, s);
 }
 
 // Batched C[z] (M x N, ldc) = A[z] (M x K, lda) * B[z]^T (N x K, ldb): the 16 Winograd-domain GEMMs.

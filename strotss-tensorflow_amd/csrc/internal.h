@@ -10,8 +10,8 @@ int st_moment_fwd_gemm(const float* cy, int krows, int ld, const float* Sx, floa
                        float* partial, int* n_partial, hipStream_t s);
 int st_moment_bwd_gemm(const float* cy, int n, int ld, const float* T, float alpha, const float* bias,
                        float bias_scale, float* dY, hipStream_t s);
-int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* x, const float* r, const float* q,
-                        int n, int ld, float g, float* dx, hipStream_t s);
+int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* bmat, const float* x, const float* r,
+                        const float* q, int n, int ld, float g, float* dx, hipStream_t s);
 
 int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                        float* C, int ldc, long long strideC, int M, int N, int K, int batch, hipStream_t s);

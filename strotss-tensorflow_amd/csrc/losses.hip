@@ -375,6 +375,112 @@ __global__ __launch_bounds__(256) void moment_finalize_kernel(const float* __res
   if (threadIdx.x == 0) loss_out[0] = a / ((float)d * (float)d) + b / (float)d;
 }
 
+// ---------------------------------------------------------------- Sinkhorn-Knopp (build-defined, see strotss_hip.h)
+// All matrices are stored pred-major: Mt[j][i], j < n (prediction row), i < ns (style row), row stride ldm.
+#define SK_EPS 1e-12f
+__global__ __launch_bounds__(256) void sk_fill_kernel(float* __restrict__ x, int n, float v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+__global__ __launch_bounds__(256) void sk_exp_kernel(const float* __restrict__ Mt, size_t total, float l,
+                                                     float* __restrict__ Kt) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) Kt[e] = __expf(-l * Mt[e]);
+}
+// out[i] = sum_j Kt[j][i] * (Mt ? Mt[j][i] * wm[j] + w[j] : w[j])   -- two-stage column reduction, stage 1
+__global__ __launch_bounds__(256) void sk_coldot_partial_kernel(const float* __restrict__ Kt, const float* __restrict__ Mt,
+                                                                int n, int ns, int ldm, const float* __restrict__ w,
+                                                                const float* __restrict__ wm, float* __restrict__ part) {
+  __shared__ float sm[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int per = (n + COL_CHUNKS - 1) / COL_CHUNKS;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  float a = 0.f;
+  if (col < ns)
+    for (int j = j0 + g; j < j1; j += 4) {
+      const size_t o = (size_t)j * ldm + col;
+      const float wj = w ? w[j] : 0.f;
+      a += Kt[o] * (Mt ? Mt[o] * wm[j] + wj : wj);
+    }
+  sm[g][c] = a;
+  __syncthreads();
+  if (g == 0 && col < ns) part[(size_t)blockIdx.y * ns + col] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+}
+// stage 2.  mode 0 (forward): a = sum -> u[i] = px / max(a, eps).
+//           mode 1 (backward): gu = sum -> da[i] = a was above eps ? -gu u[i]^2 / px : 0   (u = px / max(a, eps))
+__global__ __launch_bounds__(256) void sk_col_final_kernel(const float* __restrict__ part, int ns, int mode, float px,
+                                                           float* __restrict__ u, float* __restrict__ da) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ns) return;
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < COL_CHUNKS; ++k) a += part[(size_t)k * ns + i];
+  if (mode == 0) {
+    u[i] = px / fmaxf(a, SK_EPS);
+  } else {
+    const float ui = u[i];
+    da[i] = (ui < px / SK_EPS) ? -a * ui * ui / px : 0.f;
+  }
+}
+// b[j] = sum_i Kt[j][i] * (Mt ? Mt[j][i] : 1) * w[i], one workgroup per row j.
+// mode 0 (forward): v[j] = py / max(b, eps).
+// mode 1 (backward): gv = b -> db[j] = -gv vref[j]^2 / py (0 where vref's b was clamped); with Mt also cost[j] = vref[j] * b.
+__global__ __launch_bounds__(256) void sk_rowdot_kernel(const float* __restrict__ Kt, const float* __restrict__ Mt,
+                                                        int ns, int ldm, const float* __restrict__ w, int mode,
+                                                        float py, float* __restrict__ v,
+                                                        const float* __restrict__ vref, float* __restrict__ db,
+                                                        float* __restrict__ cost) {
+  __shared__ float red[4];
+  const int j = blockIdx.x;
+  const float* kr = Kt + (size_t)j * ldm;
+  const float* mr = Mt ? Mt + (size_t)j * ldm : nullptr;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < ns; i += 256) a += kr[i] * (mr ? mr[i] : 1.f) * w[i];
+  const float b = block_sum_256(a, red);
+  if (threadIdx.x == 0) {
+    if (mode == 0) {
+      v[j] = py / fmaxf(b, SK_EPS);
+    } else {
+      const float vj = vref[j];
+      db[j] = (vj < py / SK_EPS) ? -b * vj * vj / py : 0.f;
+      if (cost) cost[j] = vj * b;
+    }
+  }
+}
+// Gradient assembly, one workgroup per prediction row j:
+//   dM[j][i] = K (u_T[i] v_T[j] (1 - l M) - l sum_t (U_t[i] DB_t[j] + DA_t[i] V_{t-1}[j]))
+//   W[j][i] = -dM * rs[i]   (operand of the backward GEMM against the style rows),   q[j] = sum_i -dM (1 - M)
+__global__ __launch_bounds__(256) void sk_assemble_kernel(const float* __restrict__ Kt, const float* __restrict__ Mt,
+                                                          int ns, int ldm, int T, float l, const float* __restrict__ U,
+                                                          const float* __restrict__ DA, const float* __restrict__ V,
+                                                          const float* __restrict__ DB, int n,
+                                                          const float* __restrict__ rs, float* __restrict__ W,
+                                                          float* __restrict__ q) {
+  __shared__ float red[4];
+  __shared__ float dbj[64], vpj[64];
+  const int j = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += 256) { dbj[t] = DB[(size_t)t * n + j]; vpj[t] = V[(size_t)t * n + j]; }   // V[t] = v_{t-1}
+  __syncthreads();
+  const float vT = V[(size_t)T * n + j];
+  float qs = 0.f;
+  for (int i = threadIdx.x; i < ldm; i += 256) {
+    float w = 0.f;
+    if (i < ns) {
+      const size_t o = (size_t)j * ldm + i;
+      float s = 0.f;
+      for (int t = 0; t < T; ++t) s += U[(size_t)t * ns + i] * dbj[t] + DA[(size_t)t * ns + i] * vpj[t];
+      const float m = Mt[o];
+      const float dm = Kt[o] * (U[(size_t)(T - 1) * ns + i] * vT * (1.f - l * m) - l * s);
+      w = -dm;
+      qs += w * (1.f - m);
+      w *= rs[i];
+    }
+    W[(size_t)j * ldm + i] = w;
+  }
+  const float tot = block_sum_256(qs, red);
+  if (threadIdx.x == 0) q[j] = tot;
+}
+
 #define CHK(expr)            \
   do {                       \
     int rc__ = (expr);       \
@@ -415,6 +521,21 @@ struct RemdWs {
     pmin = w.take<float>((size_t)COL_CHUNKS * ldc); pcnt = w.take<float>((size_t)COL_CHUNKS * ldc);
     ys = w.take<f32x4>(ns); yp = w.take<f32x4>(n);
     sel = w.take<int>(4);
+    return w.ok();
+  }
+};
+struct SinkhornWs {
+  float *rp, *Mt, *Kt, *W, *U, *DA, *V, *DB, *part, *q, *cost;
+  int ldm;
+  bool plan(Workspace& w, int ns, int n, int T) {
+    ldm = round_up(ns, 32);
+    const int rows = round_up(n, 64);
+    rp = w.take<float>(round_up(n, 32));
+    Mt = w.take<float>((size_t)rows * ldm); Kt = w.take<float>((size_t)rows * ldm); W = w.take<float>((size_t)rows * ldm);
+    U = w.take<float>((size_t)T * ns); DA = w.take<float>((size_t)T * ns);
+    V = w.take<float>((size_t)(T + 1) * n); DB = w.take<float>((size_t)T * n);
+    part = w.take<float>((size_t)COL_CHUNKS * ns);
+    q = w.take<float>(n); cost = w.take<float>(n);
     return w.ok();
   }
 };
@@ -482,7 +603,71 @@ int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int 
                      s.qdot);
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, s.lossrow, n, 1.0f / (float)n, loss_out);
   LAUNCH_OK();
-  return st_selfsim_bwd_gemm(s.Mq, ldc, ldc, pred, s.rp, s.qdot, n, ld, gscale, gpred, st);
+  return st_selfsim_bwd_gemm(s.Mq, ldc, ldc, pred, pred, s.rp, s.qdot, n, ld, gscale, gpred, st);
+}
+
+size_t strotss_sinkhorn_workspace_bytes(int ns, int n, int n_iter) {
+  Workspace w = Workspace::planner();
+  SinkhornWs s;
+  s.plan(w, ns, n, n_iter);
+  return w.off;
+}
+
+int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n, int d,
+                                 int ld, float l, int n_iter, float gscale, float* gpred, float* loss_out,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(style && rs && pred && gpred && loss_out && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(l > 0.f && n_iter >= 1 && n_iter <= 64, STROTSS_ERANGE);
+  Workspace w(workspace, workspace_bytes);
+  SinkhornWs s;
+  ST_CHECK_ARG(s.plan(w, ns, n, n_iter), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  const int ldm = s.ldm, T = n_iter;
+  const float px = 1.0f / (float)ns, py = 1.0f / (float)n;
+  const dim3 gcol(cdiv(ns, 64), COL_CHUNKS), gfin(cdiv(ns, 256));
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+  LAUNCH_OK();
+  CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.Mt, ldm, st));          // Mt[j][i] = 1 - <yhat_j, xhat_i>
+  hipLaunchKernelGGL(sk_exp_kernel, dim3(min(4096, cdiv((size_t)n * ldm, 256))), dim3(256), 0, st, s.Mt,
+                     (size_t)n * ldm, l, s.Kt);
+  // v_0 = 1
+  hipLaunchKernelGGL(sk_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, s.V, n, 1.0f);
+  for (int t = 1; t <= T; ++t) {                     // u_t = px / (K v_{t-1}),  v_t = py / (K^T u_t)
+    hipLaunchKernelGGL(sk_coldot_partial_kernel, gcol, dim3(256), 0, st, s.Kt, (const float*)nullptr, n, ns, ldm,
+                       s.V + (size_t)(t - 1) * n, (const float*)nullptr, s.part);
+    hipLaunchKernelGGL(sk_col_final_kernel, gfin, dim3(256), 0, st, s.part, ns, 0, px, s.U + (size_t)(t - 1) * ns,
+                       (float*)nullptr);
+    hipLaunchKernelGGL(sk_rowdot_kernel, dim3(n), dim3(256), 0, st, s.Kt, (const float*)nullptr, ns, ldm,
+                       s.U + (size_t)(t - 1) * ns, 0, py, s.V + (size_t)t * n, (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr);
+  }
+  LAUNCH_OK();
+  // cost = sum_j v_T[j] ((K o M)^T u_T)[j]; the same pass gives gv -> db_T
+  const float* uT = s.U + (size_t)(T - 1) * ns;
+  const float* vT = s.V + (size_t)T * n;
+  hipLaunchKernelGGL(sk_rowdot_kernel, dim3(n), dim3(256), 0, st, s.Kt, s.Mt, ns, ldm, uT, 1, py, (float*)nullptr, vT,
+                     s.DB + (size_t)(T - 1) * n, s.cost);
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, s.cost, n, 1.0f, loss_out);
+  for (int t = T; t >= 1; --t) {
+    // gu = [t == T] (K o M) v_T + K db_t  ->  da_t ;   gv = K^T da_t  ->  db_{t-1}
+    const bool top = t == T;
+    hipLaunchKernelGGL(sk_coldot_partial_kernel, gcol, dim3(256), 0, st, s.Kt, top ? s.Mt : (const float*)nullptr, n, ns,
+                       ldm, s.DB + (size_t)(t - 1) * n, top ? vT : (const float*)nullptr, s.part);
+    hipLaunchKernelGGL(sk_col_final_kernel, gfin, dim3(256), 0, st, s.part, ns, 1, px, s.U + (size_t)(t - 1) * ns,
+                       s.DA + (size_t)(t - 1) * ns);
+    if (t > 1)
+      hipLaunchKernelGGL(sk_rowdot_kernel, dim3(n), dim3(256), 0, st, s.Kt, (const float*)nullptr, ns, ldm,
+                         s.DA + (size_t)(t - 1) * ns, 1, py, (float*)nullptr, s.V + (size_t)(t - 1) * n,
+                         s.DB + (size_t)(t - 2) * n, (float*)nullptr);
+  }
+  LAUNCH_OK();
+  const int rows = round_up(n, 64);
+  if (rows > n) CHK((int)hipMemsetAsync(s.W + (size_t)n * ldm, 0, sizeof(float) * (size_t)(rows - n) * ldm, st));
+  hipLaunchKernelGGL(sk_assemble_kernel, dim3(n), dim3(256), 0, st, s.Kt, s.Mt, ns, ldm, T, l, s.U, s.DA, s.V, s.DB, n, rs,
+                     s.W, s.q);
+  LAUNCH_OK();
+  return st_selfsim_bwd_gemm(s.W, ldm, ldm, style, pred, s.rp, s.q, n, ld, gscale, gpred, st);
 }
 
 size_t strotss_remd_workspace_bytes(int ns, int n) {

@@ -276,6 +276,15 @@ def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out):
                                      ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "remd_cos_fwd_bwd")
 
 
+def sinkhorn_cos_fwd_bwd(style, rs, ns, pred, n, d, l, n_iter, gscale, gpred, loss_out):
+    lib = _hip.lib()
+    nb = lib.strotss_sinkhorn_workspace_bytes(ns, n, n_iter)
+    ws = workspaces.get("sinkhorn", nb, pred.device)
+    check(lib.strotss_sinkhorn_cos_fwd_bwd(ptr(style), ptr(rs), ns, ptr(pred), n, d, pred.shape[1], float(l), int(n_iter),
+                                           gscale, ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()),
+          "sinkhorn_cos_fwd_bwd")
+
+
 def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out, rgb_to_yuv=True):
     l = _hip.lib()
     nb = l.strotss_remd_workspace_bytes(ns, n)

@@ -116,7 +116,21 @@ def relaxed_emd(x: torch.Tensor, y: torch.Tensor, distance: str = 'cosine') -> t
                               f"and 'both' at width 3 (what run_strotss.py uses)")
 
 
-def sinkhorn_knopp(x, y, distance: str = 'cosine', l: int = 10, N_iter: int = 30):
-    """reference losses.py:83-105 is marked `# TODO: untested`, is never called, and cannot execute
-    (`tf.ones_like(shape)` on a Python tuple).  There is no behaviour to match; not provided."""
-    raise NotImplementedError("sinkhorn_knopp is dead, non-executable code in the reference")
+def sinkhorn_knopp(x: torch.Tensor, y: torch.Tensor, distance: str = 'cosine', l: int = 10,
+                   N_iter: int = 30) -> torch.Tensor:
+    """Sinkhorn-Knopp transport cost between x (target) and y (prediction), differentiable w.r.t. y.
+    BUILD-DEFINED: reference losses.py:83-105 is marked `# TODO: untested`, is never called and cannot execute
+    (`tf.ones_like(shape)` on a Python tuple), so there is no behaviour to match; this is its evident intent
+    (K = exp(-l M), uniform marginals, N_iter alternating scalings from v = 1, cost sum(u * ((K*M) v)), gradient
+    through the iterations), pinned by the float64 autograd restatement oracle.strotss_oracle.sinkhorn_knopp.
+    Only the cosine cost is provided on the HIP path."""
+    if not l > 0:
+        raise ValueError("l must be greater than 0")
+    if distance != 'cosine':
+        raise NotImplementedError(f"sinkhorn_knopp(distance={distance!r}): the HIP path covers 'cosine'")
+    _no_grad_side(x, "sinkhorn_knopp(x, y)")
+    bx = _buf(x)
+    ns, _ = reshape_2d(x).shape
+    rs = _ops.row_inv_norm(bx, ns)
+    return _FusedLoss.apply(y, lambda bp, n, dd, g, loss: _ops.sinkhorn_cos_fwd_bwd(bx, rs, ns, bp, n, dd, l, N_iter, 1.0,
+                                                                                     g, loss))

@@ -203,7 +203,30 @@ def test_losses_api_autograd():
     with pytest.raises(NotImplementedError):
         L.self_similarity(yd, cd.clone().requires_grad_(True))
     with pytest.raises(NotImplementedError):
-        L.sinkhorn_knopp(xd, yd)
+        L.sinkhorn_knopp(xd, yd, distance='l2')
+
+
+@pytest.mark.parametrize("cfg", [(96, 80, 131, 10, 30), (64, 100, 67, 5, 12), (200, 200, 35, 10, 30)])
+def test_sinkhorn_knopp_matches_float64_autograd(cfg):
+    """Build-defined Sinkhorn cost (losses.py:83-105 is dead code in the reference): value and the gradient through
+    the iterations against the float64 autograd restatement."""
+    from nn import losses as L
+    n, ns, d, l, iters = cfg
+    rng = np.random.default_rng(n + ns)
+    mk = lambda r, c: np.abs(rng.standard_normal((r, c))) + 0.01
+    x, y = mk(ns, d), mk(n, d)
+    xt = torch.from_numpy(x)
+    yt = torch.from_numpy(y).clone().requires_grad_(True)
+    ref = O.sinkhorn_knopp(xt, yt, 'cosine', float(l), iters)
+    gref, = torch.autograd.grad(ref, yt)
+    yd = torch.from_numpy(y).float().to(DEV).requires_grad_(True)
+    got = L.sinkhorn_knopp(torch.from_numpy(x).float().to(DEV), yd, 'cosine', l, iters)
+    got.backward()
+    assert abs(float(got) - float(ref)) < 2e-4 * abs(float(ref)), (float(got), float(ref))
+    rel = float((yd.grad.cpu().double() - gref).norm() / gref.norm())
+    assert rel < 2e-3, rel
+    with pytest.raises(ValueError):
+        L.sinkhorn_knopp(torch.from_numpy(x).float().to(DEV), yd, 'cosine', 0)
 
 
 def test_vgg_and_pyramid_api_autograd():

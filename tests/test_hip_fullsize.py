@@ -211,3 +211,19 @@ def test_engine_step_invariants_1024():
         assert torch.equal(ref, eng.gvars[k])
     for a, b in zip(eng.variables, before):
         assert float((a - b).abs().max()) <= 10 * eng.lr * 1.0001
+
+
+def test_sinkhorn_fullsize_permutation_invariance_and_bounds():
+    """N = 1024, D = 2179: the Sinkhorn cost does not depend on the order of the prediction rows, its gradient
+    permutes with them, and a plan with uniform marginals costs at least the relaxed-EMD bound."""
+    from nn import losses as L
+    x, y = _feat(11)[:N, :D].contiguous(), _feat(12)[:N, :D].contiguous()
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(3)).to(DEV)
+    ya = y.clone().requires_grad_(True)
+    yb = y[perm].clone().requires_grad_(True)
+    ca, cb = L.sinkhorn_knopp(x, ya), L.sinkhorn_knopp(x, yb)
+    ca.backward(); cb.backward()
+    assert abs(float(ca) - float(cb)) < 1e-4 * abs(float(ca))
+    rel = float((ya.grad[perm] - yb.grad).norm() / yb.grad.norm())
+    assert rel < 1e-3, rel
+    assert float(ca) >= float(L.relaxed_emd(x, y)) - 1e-5

@@ -126,3 +126,24 @@ def test_rmsprop_first_step():
         p.grad = gk.clone(); opt.step()
         O.rmsprop_update(v2, r2, gk, 2e-3)
     assert torch.allclose(p.detach(), v2, rtol=1e-12, atol=0)
+
+
+def test_sinkhorn_oracle_properties():
+    """The build-defined Sinkhorn restatement: marginals of the plan after the last v-update, permutation
+    invariance, and the small-regularisation limit approaching the relaxed EMD lower bound from above."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(40, 16, generator=g, dtype=torch.float64) + 0.05
+    y = torch.rand(48, 16, generator=g, dtype=torch.float64) + 0.05
+    c = O.sinkhorn_knopp(x, y, 'cosine', 10.0, 200)
+    perm = torch.randperm(48, generator=g)
+    assert abs(float(O.sinkhorn_knopp(x, y[perm], 'cosine', 10.0, 200)) - float(c)) < 1e-12
+    M = O.cosine_distance(x, y)
+    K = torch.exp(-10.0 * M)
+    u = torch.ones(40, 1, dtype=torch.float64); v = torch.ones(48, 1, dtype=torch.float64)
+    for _ in range(200):
+        u = (1 / 40) / (K @ v); v = (1 / 48) / (K.t() @ u)
+    P = u * K * v.t()
+    assert (P.sum(0) - 1 / 48).abs().max() < 1e-12 and (P.sum(1) - 1 / 40).abs().max() < 1e-6
+    assert abs(float((P * M).sum()) - float(c)) < 1e-12
+    # a transport plan with uniform marginals can never cost less than either relaxed bound
+    assert float(c) >= float(torch.amin(M, 1).mean()) - 1e-12 and float(c) >= float(torch.amin(M, 0).mean()) - 1e-12

@@ -390,17 +390,24 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* _
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+    // all 14 gathers of this lane first, branch-free (clamped address, zero-select afterwards): behind a branch
+    // every load would be followed by its own s_waitcnt and the 14 latencies would add up
+    float av[14];
+    bool okv[14];
+    int chv[14];
 #pragma unroll
     for (int s2 = 0; s2 < 14; ++s2) {
       // this lane's k = 2*s2 + hh  ->  (tap, channel); both candidates are compile-time, hh selects
       const int k0 = 2 * s2, k1 = 2 * s2 + 1;
       const int tap = hh ? k1 / 3 : k0 / 3, ch = hh ? k1 % 3 : k0 % 3;
-      float a = 0.f;
-      if (tap < 9) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        if (live && yy >= 0 && yy < H && xx >= 0 && xx < W)
-          a = (img[((size_t)yy * W + xx) * 3 + ch] - mean[ch]) * istd[ch];
-      }
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      const bool ok = live && tap < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      okv[s2] = ok; chv[s2] = ch;
+      av[s2] = img[ok ? ((size_t)yy * W + xx) * 3 + ch : 0];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 14; ++s2) {
+      const float a = okv[s2] ? (av[s2] - mean[chv[s2]]) * istd[chv[s2]] : 0.f;
       const float w0 = wsm[(2 * s2 + hh) * 64 + l31], w1 = wsm[(2 * s2 + hh) * 64 + 32 + l31];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc1, 0, 0, 0);
@@ -427,51 +434,69 @@ __global__ __launch_bounds__(512) void conv3x3_c3_dgrad_lds_kernel(const float* 
                                                                    const float* __restrict__ w_tic, f32x4 istd,
                                                                    float* __restrict__ gimg, int accumulate) {
   __shared__ __attribute__((aligned(16))) float tile[(C3D_TH + 2) * (C3D_TW + 2) * C3D_PS];
-  __shared__ __attribute__((aligned(16))) float wsm[27 * 64];
   const int t = threadIdx.x;
-  for (int i = t; i < 27 * 64; i += 512) wsm[i] = w_tic[i];
   const int tiles_x = (W + C3D_TW - 1) / C3D_TW;
   const int ty0 = (blockIdx.x / tiles_x) * C3D_TH, tx0 = (blockIdx.x % tiles_x) * C3D_TW;
   // stage (TH+2) x (TW+2) pixels x 64 channels, zero outside the image
   constexpr int NPIX = (C3D_TH + 2) * (C3D_TW + 2);
-  for (int e = t; e < NPIX * 16; e += 512) {
+  constexpr int NST = (NPIX * 16 + 511) / 512;     // loads per thread, issued as one batch (clamped, zero-selected)
+  f32x4 sv[NST];
+  bool sok[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = t + 512 * i;
     const int pix = e >> 4, c4 = e & 15;
     const int py = pix / (C3D_TW + 2), px = pix - py * (C3D_TW + 2);
     const int y = ty0 + py - 1, x = tx0 + px - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const f32x4*>(&gout[((size_t)y * W + x) * 64 + c4 * 4]);
-    *reinterpret_cast<f32x4*>(&tile[pix * C3D_PS + c4 * 4]) = v;
+    sok[i] = e < NPIX * 16 && y >= 0 && y < H && x >= 0 && x < W;
+    sv[i] = *reinterpret_cast<const f32x4*>(&gout[sok[i] ? ((size_t)y * W + x) * 64 + c4 * 4 : 0]);
+  }
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = t + 512 * i;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (e < NPIX * 16) *reinterpret_cast<f32x4*>(&tile[(e >> 4) * C3D_PS + (e & 15) * 4]) = sok[i] ? sv[i] : z;
   }
   __syncthreads();
-  const int sub = t & 3, lp = t >> 2;            // 128 pixels x 4 channel quarters
+  // wave = (pixel half, channel quarter): the quarter is wave-uniform, so its 3 x 16 weights per tap come through
+  // the scalar cache as SGPR operands of the FMAs instead of three more LDS reads per staged value (that form was
+  // LDS-bandwidth-bound at 134 us for a 1024^2 image); the four quarters of a pixel meet in LDS at the end
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int cq = wave & 3, lp = (wave >> 2) * 64 + lane;          // 128 pixels
   const int ly = lp / C3D_TW, lx = lp - ly * C3D_TW;
-  const int y = ty0 + ly, x = tx0 + lx;
-  const int co0 = sub * 16;
+  const float* wq = w_tic + cq * 16;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    const float* q = &tile[((ly + tap / 3) * (C3D_TW + 2) + lx + tap % 3) * C3D_PS + co0];
-    const float* w0 = &wsm[(tap * 3 + 0) * 64 + co0];
-    const float* w1 = &wsm[(tap * 3 + 1) * 64 + co0];
-    const float* w2 = &wsm[(tap * 3 + 2) * 64 + co0];
+    const float* q = &tile[((ly + tap / 3) * (C3D_TW + 2) + lx + tap % 3) * C3D_PS + cq * 16];
+    const float* w0 = wq + (tap * 3 + 0) * 64;
+    const float* w1 = wq + (tap * 3 + 1) * 64;
+    const float* w2 = wq + (tap * 3 + 2) * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 gv = *reinterpret_cast<const f32x4*>(q + 4 * g);
-      const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + 4 * g);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + 4 * g);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(w2 + 4 * g);
-      s0 += gv[0] * a[0] + gv[1] * a[1] + gv[2] * a[2] + gv[3] * a[3];
-      s1 += gv[0] * b[0] + gv[1] * b[1] + gv[2] * b[2] + gv[3] * b[3];
-      s2 += gv[0] * c[0] + gv[1] * c[1] + gv[2] * c[2] + gv[3] * c[3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s0 += gv[k] * w0[4 * g + k];
+        s1 += gv[k] * w1[4 * g + k];
+        s2 += gv[k] * w2[4 * g + k];
+      }
     }
   }
-  s0 += __shfl_xor(s0, 1, 64); s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
-  s0 += __shfl_xor(s0, 2, 64); s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
-  if (sub == 0 && y < H && x < W) {
-    float* g = gimg + ((size_t)y * W + x) * 3;
-    const float a0 = s0 * istd[0], a1 = s1 * istd[1], a2 = s2 * istd[2];
-    if (accumulate) { g[0] += a0; g[1] += a1; g[2] += a2; }
-    else { g[0] = a0; g[1] = a1; g[2] = a2; }
+  __shared__ float red[4][C3D_TH * C3D_TW][3];
+  red[cq][lp][0] = s0; red[cq][lp][1] = s1; red[cq][lp][2] = s2;
+  __syncthreads();
+  if (t < C3D_TH * C3D_TW) {
+    const int py = t / C3D_TW, px = t - py * C3D_TW;
+    const int y = ty0 + py, x = tx0 + px;
+    if (y < H && x < W) {
+      float* g = gimg + ((size_t)y * W + x) * 3;
+      const float a0 = ((red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0])) * istd[0];
+      const float a1 = ((red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1])) * istd[1];
+      const float a2 = ((red[0][t][2] + red[1][t][2]) + (red[2][t][2] + red[3][t][2])) * istd[2];
+      if (accumulate) { g[0] += a0; g[1] += a1; g[2] += a2; }
+      else { g[0] = a0; g[1] = a1; g[2] = a2; }
+    }
   }
 }
 

@@ -94,9 +94,11 @@ size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout,
 /* u_prk: (36, rows, k) -> u_packed[p][rows/32][k/8][2][32][4]: element (p, r, c) at
  * ((((p * (rows/32) + r/32) * (k/8) + c/8) * 2 + (c%8)/4) * 32 + r%32) * 4 + c%4.  rows % 32 == 0, k % 8 == 0. */
 int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_packed, void* stream);
+/* pool_out (may be NULL): also writes strotss_maxpool2_fwd(out) = the (h/2, w/2, cout) input of the next block --
+ * from the registers of the fused kernel's epilogue where that kernel runs, by a pooling launch otherwise. */
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok,
                                  const float* u_packed, const float* bias, int cout, int tile_m, float* out,
-                                 void* workspace, size_t workspace_bytes, void* stream);
+                                 float* pool_out, void* workspace, size_t workspace_bytes, void* stream);
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
                                    const float* u_packed, int cin, int tile_m, const float* act_in, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream);

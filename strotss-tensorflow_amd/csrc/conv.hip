@@ -609,6 +609,14 @@ int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const fl
   ST_LAUNCH_RET();
 }
 
+}  // extern "C"
+
+int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, hipStream_t st) {
+  return strotss_maxpool2_fwd(in, h, w, c, out, (void*)st);
+}
+
+extern "C" {
+
 int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, void* stream) {
   ST_CHECK_ARG(in && out && h >= 2 && w >= 2 && c > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(c % 4 == 0, STROTSS_EALIGN);

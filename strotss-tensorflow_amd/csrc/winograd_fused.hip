@@ -87,7 +87,7 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
                                                                 const float* __restrict__ U, int Cout,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ mask, int relu,
-                                                                float* __restrict__ out, int RW, int NG, int nitems) {
+                                                                float* __restrict__ out, float* __restrict__ pool, int RW, int NG, int nitems) {
   __shared__ __attribute__((aligned(16))) float lds[F_LDS_FLOATS];
   float* const Vb = lds;                            // V[2]
   float* const Rb = lds + 2 * F_V;                  // raw[2]
@@ -374,6 +374,22 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
               if (yb + r < H && xb + c < W)
                 op[(r * W + c) * Cout] = ((keep >> (4 * r + c)) & 1u) ? fmaxf(Y[i][r][c], lo) : 0.f;
         }
+        if constexpr (!MASK) {
+          // fused 2x2/2 max-pool of the activations just written (the tile's 4x4 outputs hold 2x2 windows);
+          // windows are emitted only where they lie inside the image (floor pooling)
+          if (pool) {
+            const int PH = H >> 1, PW = W >> 1, py0 = yb >> 1, px0 = xb >> 1;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+              for (int pc = 0; pc < 2; ++pc)
+                if (py0 + pr < PH && px0 + pc < PW) {
+                  const float m0 = fmaxf(Y[i][2 * pr][2 * pc], Y[i][2 * pr][2 * pc + 1]);
+                  const float m1 = fmaxf(Y[i][2 * pr + 1][2 * pc], Y[i][2 * pr + 1][2 * pc + 1]);
+                  pool[((size_t)(py0 + pr) * PW + px0 + pc) * Cout + co] = fmaxf(fmaxf(m0, m1), lo);
+                }
+          }
+        }
       }
     }
     PROF(5); PROF(6); ++prof_ph;
@@ -418,7 +434,7 @@ bool st_winograd43_fused_enabled(int h, int w, int cout) {
 }
 
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
-                        const float* mask, int relu, float* out, hipStream_t st) {
+                        const float* mask, int relu, float* out, float* pool_out, hipStream_t st) {
   if (cin % 32 != 0 || cout % 32 != 0) return STROTSS_EALIGN;
   if ((size_t)h * w * cin >= ((size_t)1 << 30) || (size_t)h * w * cout >= ((size_t)1 << 30)) return STROTSS_EALIGN;
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
@@ -436,9 +452,9 @@ int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, 
   while (grid > 8 && grid / 2 >= nitems) grid /= 2;
   if (mask)
     hipLaunchKernelGGL(winograd43_fused_kernel<true>, dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, cin, U, cout,
-                       bias, mask, relu, out, RW, NG, nitems);
+                       bias, mask, relu, out, pool_out, RW, NG, nitems);
   else
     hipLaunchKernelGGL(winograd43_fused_kernel<false>, dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, cin, U, cout,
-                       bias, mask, relu, out, RW, NG, nitems);
+                       bias, mask, relu, out, pool_out, RW, NG, nitems);
   ST_LAUNCH_RET();
 }

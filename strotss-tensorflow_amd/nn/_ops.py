@@ -127,8 +127,9 @@ def winograd_packed(u: torch.Tensor):
     return up
 
 
-def conv3x3_winograd_fwd(x, u_pok, bias, out=None):
-    """u_pok: (16, cout, cin) -> F(2x2,3x3), (36, cout, cin) -> F(4x4,3x3)."""
+def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None):
+    """u_pok: (16, cout, cin) -> F(2x2,3x3), (36, cout, cin) -> F(4x4,3x3).  pool_out: (1, h//2, w//2, cout) buffer
+    that also receives the 2x2/2 max-pool of the result."""
     require(x, "conv input"); h, w, cin = hwc(x)
     cout = bias.numel()
     if out is None:
@@ -136,7 +137,8 @@ def conv3x3_winograd_fwd(x, u_pok, bias, out=None):
     m = _tile_m(u_pok)
     ws, nb = _wino_ws(h, w, cin, cout, m, x.device)
     check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(winograd_packed(u_pok)), ptr(bias),
-                                                  cout, m, ptr(out), ptr(ws), nb, stream_ptr()), "conv3x3_winograd_fwd")
+                                                  cout, m, ptr(out), ptr(pool_out), ptr(ws), nb, stream_ptr()),
+          "conv3x3_winograd_fwd")
     return out
 
 

@@ -207,9 +207,11 @@ class VGGTrunk:
     def forward(self, img: torch.Tensor) -> List[torch.Tensor]:
         self.img = img
         P = self.p
-        for step in self.plan:
+        pooled = set()                  # pools already written by the conv before them
+        for si, step in enumerate(self.plan):
             if step[0] == 'pool':
-                _ops.maxpool2_fwd(self.acts[step[2]], out=self.pools[step[1]])
+                if step[1] not in pooled:
+                    _ops.maxpool2_fwd(self.acts[step[2]], out=self.pools[step[1]])
             else:
                 _, li, src = step
                 L = P.layers[li]
@@ -217,7 +219,13 @@ class VGGTrunk:
                 if L["cin"] == 3:
                     _ops.conv3x3_c3_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li], mean=P.mean, std=P.std)
                 elif self.wtile[li]:
-                    _ops.conv3x3_winograd_fwd(x, L["u_fwd"][self.wtile[li]], L["bias"], out=self.acts[li])
+                    nxt = self.plan[si + 1] if si + 1 < len(self.plan) else None
+                    pool_out = None
+                    if nxt is not None and nxt[0] == 'pool' and nxt[2] == li:     # the pool of this layer rides along
+                        pool_out = self.pools[nxt[1]]
+                        pooled.add(nxt[1])
+                    _ops.conv3x3_winograd_fwd(x, L["u_fwd"][self.wtile[li]], L["bias"], out=self.acts[li],
+                                              pool_out=pool_out)
                 else:
                     _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
         return [self.acts[i] for i in self.taps]

@@ -143,6 +143,10 @@ def test_conv_winograd_fwd_and_dgrad(ops, cfg, tile_m):
     u_f = ops.winograd_weights(wt.permute(3, 2, 0, 1), tile_m).cuda()
     got = ops.conv3x3_winograd_fwd(dev(x), u_f, dev(b)).cpu().numpy()
     assert rel_err(got, y.detach().numpy()) < tol
+    if h >= 2 and w >= 2:                  # the pooled copy riding along (fused epilogue or a pooling launch)
+        pooled = torch.full((1, h // 2, w // 2, cout), -1.0, device="cuda")
+        got2 = ops.conv3x3_winograd_fwd(dev(x), u_f, dev(b), pool_out=pooled)
+        assert torch.equal(pooled, ops.maxpool2_fwd(got2))
     gy = torch.randn(1, h, w, cout, generator=g, dtype=torch.float64)
     ypre = _conv_ref(xin, wt, b, relu=False)
     (ypre * gy).sum().backward()

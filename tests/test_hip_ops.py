@@ -341,3 +341,19 @@ def test_rmsprop_and_postprocess(ops):
     assert got.dtype == np.uint8 and got.shape == ref.shape
     diff = np.abs(got.astype(int) - ref.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.01    # truncation boundary cases only
+
+
+def test_fused_winograd_kernel_on_every_shape():
+    """The fused F(4x4,3x3) kernel is chosen by a size policy that the small shapes of this file never meet; force it
+    (STROTSS_WINO_FUSED=2 is read once per process) and run the Winograd parity tests again in a child process:
+    odd sizes, 32..512 channels, forward with bias/ReLU and pooled copy, data-gradient with and without ReLU mask."""
+    import os, subprocess, sys
+    if os.environ.get("STROTSS_WINO_FUSED") == "2":
+        pytest.skip("already inside the forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STROTSS_WINO_FUSED="2")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_ops.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "test_conv_winograd_fwd_and_dgrad"], env=env, cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

@@ -421,7 +421,8 @@ int st_winograd43_pack(const float* u_prk, int rows, int k, float* u_packed, hip
 }
 
 // Policy (measured per layer, tools/conv_bench.py): the fused kernel wins where the three-kernel form is bound by
-// its transform traffic -- up to 256 output channels -- and there are at least two work items per CU.
+// its transform traffic -- up to 256 output channels -- and there are at least 128 work items (measured at the
+// 256 / 512 px scales: 128 and 256 beat 512 and 64 by 3-5 % of the step; STROTSS_WINO_FUSED_MIN_ITEMS overrides).
 // STROTSS_WINO_FUSED: 0 = never, 1 (default) = that policy, 2 = every layer it supports.
 bool st_winograd43_fused_enabled(int h, int w, int cout) {
   static int on = -1;
@@ -430,7 +431,9 @@ bool st_winograd43_fused_enabled(int h, int w, int cout) {
   if (on >= 2) return true;
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const long items = (long)((TH + F_TR - 1) / F_TR) * ((TW + F_TC - 1) / F_TC) * (cout / 32);
-  return cout <= 256 && items >= 512;
+  static long min_items = -1;
+  if (min_items < 0) { const char* e = getenv("STROTSS_WINO_FUSED_MIN_ITEMS"); min_items = e ? atol(e) : 128; }
+  return cout <= 256 && items >= min_items;
 }
 
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,

@@ -351,12 +351,29 @@ int st_selfsim_bwd_gemm(const float* Mq, int ldm, int kpad, const float* bmat, c
   return launch<64, 64, true, false>(Mq, ldm, n, bmat, ld, ld, kpad, e, s);
 }
 
-// Batched C[z] (M x N, ldc) = A[z] (M x K, lda) * B[z]^T (N x K, ldb): the 16 Winograd-domain GEMMs.
+// Batched C[z] (M x N, ldc) = A[z] (M x K, lda) * B[z]^T (N x K, ldb): the 16 / 36 Winograd-domain GEMMs.
 int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB,
                        float* C, int ldc, long long strideC, int M, int N, int K, int batch, hipStream_t s) {
   EpiScaleStore e{C, ldc, M, N, 1.0f, strideC};
-  if ((long long)cdiv(M, 128) * cdiv(N, 128) * batch >= 512 && N % 128 == 0)
+  const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128);
+  if (t128 * batch >= 512 && N % 128 == 0) {
+    // 128x128 tiles run two workgroups per CU: 512 slots.  When the tile count ends in a fraction of a round (512-channel
+    // layers at 1024 px: 36 x 32 = 1152 = 2.25 rounds), the whole batches that fill complete rounds go first and the
+    // remaining batches run as 128x64 tiles, whose shorter workgroups make the tail half as long.
+    static int split = -1;
+    if (split < 0) { const char* env = getenv("STROTSS_GEMM_TAIL_SPLIT"); split = env ? atoi(env) : 1; }
+    const long long slots = 512, total = t128 * batch;
+    const long long rem = total % slots;
+    if (split && total > slots && rem != 0 && rem * 2 <= slots && slots % t128 == 0) {
+      const int tail = (int)(rem / t128), head = batch - tail;
+      int rc = launch_pipe<128, 128>(A, lda, M, strideA, B, ldb, N, strideB, K, head, e, s);
+      if (rc != 0) return rc;
+      EpiScaleStore e2{C + (long long)head * strideC, ldc, M, N, 1.0f, strideC};
+      return launch_pipe<128, 64>(A + (long long)head * strideA, lda, M, strideA, B + (long long)head * strideB, ldb, N,
+                                  strideB, K, tail, e2, s);
+    }
     return launch_pipe<128, 128>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
+  }
   if ((long long)cdiv(M, 128) * cdiv(N, 64) * batch >= 512)
     return launch_pipe<128, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
   return launch_pipe<64, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);

@@ -374,8 +374,22 @@ int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* 
     }
     return launch_pipe<128, 128>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
   }
-  if ((long long)cdiv(M, 128) * cdiv(N, 64) * batch >= 512)
+  const long long t64 = (long long)cdiv(M, 128) * cdiv(N, 64);
+  if (t64 * batch >= 512) {
+    // same idea one size down (512-channel layers at 64x64 px: 36 x 16 = 576 = 1.125 rounds of two 128x64 workgroups per CU)
+    static int split = -1;
+    if (split < 0) { const char* env = getenv("STROTSS_GEMM_TAIL_SPLIT"); split = env ? atoi(env) : 1; }
+    const long long slots = 512, total = t64 * batch, rem = total % slots;
+    if (split && total > slots && rem != 0 && rem * 2 <= slots && slots % t64 == 0) {
+      const int tail = (int)(rem / t64), head = batch - tail;
+      int rc = launch_pipe<128, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, head, e, s);
+      if (rc != 0) return rc;
+      EpiScaleStore e2{C + (long long)head * strideC, ldc, M, N, 1.0f, strideC};
+      return launch_pipe<64, 64>(A + (long long)head * strideA, lda, M, strideA, B + (long long)head * strideB, ldb, N,
+                                 strideB, K, tail, e2, s);
+    }
     return launch_pipe<128, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
+  }
   return launch_pipe<64, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
 }
 

@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void remd_select_kernel(const float* __restric
 #define REMD_MAX_LIST 2048
 // One block per pred sample j.  Builds the (ordered) list of style rows whose cost entry
 // carries gradient for column j, then dY_j += g * ry_j (ghat - yhat (yhat.ghat)), ghat = -sum w xhat_i.
+// C is the PRED-major cost matrix Ct[j][i] (row j contiguous: the two scans of "column j" are coalesced).
 __global__ __launch_bounds__(256) void remd_cos_bwd_kernel(
     const float* __restrict__ C, int ldc, const float* __restrict__ style, const float* __restrict__ rs,
     int ns, const float* __restrict__ pred, const float* __restrict__ rp, int n, int ld,
@@ -194,20 +195,27 @@ __global__ __launch_bounds__(256) void remd_cos_bwd_kernel(
   const float cm = cmin[j], cc = ccnt[j];
   int c = 0;
   for (int i = i0; i < i1; ++i) {
-    const float v = C[(size_t)i * ldc + j];
+    const float v = C[(size_t)j * ldc + i];
     c += row_branch ? (v == rmin[i]) : (v == cm);
   }
-  cnts[t] = c;
+  // exclusive prefix of the per-thread counts: shuffle scan inside the wave + the 4 wave totals through LDS (ordered)
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if ((t & 63) >= o) incl += up;
+  }
+  if ((t & 63) == 63) cnts[t >> 6] = incl;
   __syncthreads();
-  int off = 0, total = 0;
-  for (int k = 0; k < 256; ++k) {
-    const int ck = cnts[k];
-    off += (k < t) ? ck : 0;
-    total += ck;
+  int off = incl - c, total = 0;
+#pragma unroll
+  for (int wv = 0; wv < 4; ++wv) {
+    off += (wv < (t >> 6)) ? cnts[wv] : 0;
+    total += cnts[wv];
   }
   float qpart = 0.f;
   for (int i = i0; i < i1; ++i) {
-    const float v = C[(size_t)i * ldc + j];
+    const float v = C[(size_t)j * ldc + i];
     const bool hit = row_branch ? (v == rmin[i]) : (v == cm);
     if (hit) {
       const float w = row_branch ? 1.0f / ((float)ns * rcnt[i]) : 1.0f / ((float)n * cc);
@@ -511,14 +519,16 @@ struct RemdWs {
   float *rp, *C, *rmin, *rcnt, *cmin, *ccnt, *pmin, *pcnt;
   f32x4 *ys, *yp;
   int* sel;
-  int ldc;
+  int ldc, ldt;        // row stride of the style-major C[i][j] (palette) / of the pred-major Ct[j][i] (cosine REMD)
   bool plan(Workspace& w, int ns, int n) {
     ldc = round_up(n, 32);
+    ldt = round_up(ns, 32);
+    const int ldm = ldc > ldt ? ldc : ldt;
     rp = w.take<float>(ldc);
-    C = w.take<float>((size_t)ns * ldc);
-    rmin = w.take<float>(ns); rcnt = w.take<float>(ns);
+    C = w.take<float>((size_t)ns * ldc > (size_t)n * ldt ? (size_t)ns * ldc : (size_t)n * ldt);
+    rmin = w.take<float>(ldt); rcnt = w.take<float>(ldt);
     cmin = w.take<float>(ldc); ccnt = w.take<float>(ldc);
-    pmin = w.take<float>((size_t)COL_CHUNKS * ldc); pcnt = w.take<float>((size_t)COL_CHUNKS * ldc);
+    pmin = w.take<float>((size_t)COL_CHUNKS * ldm); pcnt = w.take<float>((size_t)COL_CHUNKS * ldm);
     ys = w.take<f32x4>(ns); yp = w.take<f32x4>(n);
     sel = w.take<int>(4);
     return w.ok();
@@ -691,14 +701,18 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   const int ldc = s.ldc;
   hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
   LAUNCH_OK();
-  CHK(st_cosine_distance(style, rs, ns, pred, s.rp, n, ld, s.C, ldc, st));
-  hipLaunchKernelGGL(row_min_kernel, dim3(ns), dim3(256), 0, st, s.C, n, ldc, s.rmin, s.rcnt);
-  hipLaunchKernelGGL(col_min_partial_kernel, dim3(cdiv(n, 64), COL_CHUNKS), dim3(256), 0, st, s.C, ns, n, ldc, s.pmin,
+  // pred-major cost matrix Ct[j][i] (bitwise the transpose of cosine_distance(style, pred): same products, same k
+  // order), so that the backward kernel's scans of "column j" are contiguous: minima over i per prediction row j
+  // are row minima (cmin), minima over j per style row i column minima (rmin)
+  const int ldt = s.ldt;
+  CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.C, ldt, st));
+  hipLaunchKernelGGL(row_min_kernel, dim3(n), dim3(256), 0, st, s.C, ns, ldt, s.cmin, s.ccnt);
+  hipLaunchKernelGGL(col_min_partial_kernel, dim3(cdiv(ns, 64), COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.pmin,
                      s.pcnt);
-  hipLaunchKernelGGL(col_min_final_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, s.pmin, s.pcnt, n, ldc, s.cmin,
-                     s.ccnt);
+  hipLaunchKernelGGL(col_min_final_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin,
+                     s.rcnt);
   hipLaunchKernelGGL(remd_select_kernel, dim3(1), dim3(256), 0, st, s.rmin, ns, s.cmin, n, loss_out, s.sel);
-  hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldc, style, rs, ns, pred, s.rp, n,
+  hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldt, style, rs, ns, pred, s.rp, n,
                      ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
   ST_LAUNCH_RET();
 }

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
   float* const Vb = lds;                            // V[2]
   float* const Rb = lds + 2 * F_V;                  // raw[2]
   float* const Sx = lds + 2 * F_V + 2 * F_RAW;      // exchange
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // scalar: the per-phase address arithmetic runs on the SALU
   const int l31 = lane & 31, hh = lane >> 5;
 
   // items of this workgroup: XCD x = blockIdx % 8 owns [x * per, (x + 1) * per), its workgroups interleave them

@@ -95,19 +95,23 @@ size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout,
  * ((((p * (rows/32) + r/32) * (k/8) + c/8) * 2 + (c%8)/4) * 32 + r%32) * 4 + c%4.  rows % 32 == 0, k % 8 == 0. */
 int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_packed, void* stream);
 /* pool_out (may be NULL): also writes strotss_maxpool2_fwd(out) = the (h/2, w/2, cout) input of the next block --
- * from the registers of the fused kernel's epilogue where that kernel runs, by a pooling launch otherwise. */
+ * from the registers of the fused kernel's epilogue where that kernel runs, by a pooling launch otherwise;
+ * pool_code (may be NULL, needs pool_out): the argmax codes of that pooling, see strotss_maxpool2_fwd. */
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok,
                                  const float* u_packed, const float* bias, int cout, int tile_m, float* out,
-                                 float* pool_out, void* workspace, size_t workspace_bytes, void* stream);
+                                 float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
                                    const float* u_packed, int cin, int tile_m, const float* act_in, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream);
-/* 2x2/2 VALID max-pool: out(h/2, w/2, c). */
-int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, void* stream);
+/* 2x2/2 VALID max-pool: out(h/2, w/2, c).  code (may be NULL): (h/2, w/2, c) bytes, the index 0..3 of the FIRST
+ * max of each window in scan order (0,0),(0,1),(1,0),(1,1), or 4 when that max is not positive. */
+int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, void* stream);
 /* gin(h,w,c) = route gout(h/2,w/2,c) to the first max of each window, times (act > 0) where
- * act(h,w,c) is the pooled layer's input (post-ReLU).  Overwrites gin. */
+ * act(h,w,c) is the pooled layer's input (post-ReLU).  Overwrites gin.  With code != NULL (from the forward pass)
+ * act is not read (may be NULL): 1 byte instead of 16 per pooled element. */
 int strotss_maxpool2_bwd(const float* act, int h, int w, int c, const float* gout, float* gin,
-                         void* stream);
+                         const unsigned char* code, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sampling._sample: hypercolumn gather  (nn/strotss_utils.py:25-81) and its adjoint

@@ -501,8 +501,10 @@ __global__ __launch_bounds__(512) void conv3x3_c3_dgrad_lds_kernel(const float* 
 }
 
 // ---------------------------------------------------------------- 2x2/2 VALID max-pool
+// code (optional, one byte per pooled element): index 0..3 of the window's FIRST max in scan order (0,0),(0,1),(1,0),(1,1),
+// or 4 when that max is not positive (no gradient) -- all the backward pass needs instead of re-reading the activations
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ in, int H, int W, int C4,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, unsigned* __restrict__ code) {
   const int Ho = H >> 1, Wo = W >> 1;
   const size_t total = (size_t)Ho * Wo * C4;
   const f32x4* src = reinterpret_cast<const f32x4*>(in);
@@ -517,6 +519,45 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
     dst[e] = m;
+    if (code) {
+      unsigned packed = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v[4] = {v00[k], v01[k], v10[k], v11[k]};
+        int best = 0;
+        float bv = v[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (v[q] > bv) { bv = v[q]; best = q; }
+        packed |= (unsigned)(bv > 0.f ? best : 4) << (8 * k);
+      }
+      code[e] = packed;
+    }
+  }
+}
+// backward from the forward pass's argmax codes: reads gout + 1 byte per pooled element instead of the activations
+__global__ __launch_bounds__(256) void maxpool2_bwd_code_kernel(const unsigned* __restrict__ code, int H, int W, int C4,
+                                                                const float* __restrict__ gout,
+                                                                float* __restrict__ gin) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const size_t total = (size_t)H * W * C4;
+  const f32x4* g = reinterpret_cast<const f32x4*>(gout);
+  f32x4* dst = reinterpret_cast<f32x4*>(gin);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C4);
+    const size_t pix = e / C4;
+    const int x = (int)(pix % W), y = (int)(pix / W);
+    const int oy = y >> 1, ox = x >> 1;
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (oy < Ho && ox < Wo) {
+      const size_t po = ((size_t)oy * Wo + ox) * C4 + c;
+      const unsigned me = (unsigned)(((y & 1) << 1) | (x & 1));
+      const unsigned cd = code[po];
+      const f32x4 go = g[po];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = (((cd >> (8 * k)) & 0xffu) == me) ? go[k] : 0.f;
+    }
+    dst[e] = r;
   }
 }
 // gin[y,x,c] = (this pixel is the FIRST max of its window, scan order (0,0),(0,1),(1,0),(1,1))
@@ -611,27 +652,32 @@ int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const fl
 
 }  // extern "C"
 
-int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, hipStream_t st) {
-  return strotss_maxpool2_fwd(in, h, w, c, out, (void*)st);
+int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, hipStream_t st) {
+  return strotss_maxpool2_fwd(in, h, w, c, out, code, (void*)st);
 }
 
 extern "C" {
 
-int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, void* stream) {
+int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, void* stream) {
   ST_CHECK_ARG(in && out && h >= 2 && w >= 2 && c > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(c % 4 == 0, STROTSS_EALIGN);
   const size_t total = (size_t)(h / 2) * (w / 2) * (c / 4);
   hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(min((size_t)8192, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, in, h, w, c / 4, out);
+                     (hipStream_t)stream, in, h, w, c / 4, out, reinterpret_cast<unsigned*>(code));
   ST_LAUNCH_RET();
 }
 
-int strotss_maxpool2_bwd(const float* act, int h, int w, int c, const float* gout, float* gin, void* stream) {
-  ST_CHECK_ARG(act && gout && gin && h >= 2 && w >= 2 && c > 0, STROTSS_EINVAL);
+int strotss_maxpool2_bwd(const float* act, int h, int w, int c, const float* gout, float* gin,
+                         const unsigned char* code, void* stream) {
+  ST_CHECK_ARG((act || code) && gout && gin && h >= 2 && w >= 2 && c > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(c % 4 == 0, STROTSS_EALIGN);
   const size_t total = (size_t)h * w * (c / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(min((size_t)8192, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, act, h, w, c / 4, gout, gin);
+  const dim3 grid((unsigned)min((size_t)8192, (total + 255) / 256));
+  if (code)
+    hipLaunchKernelGGL(maxpool2_bwd_code_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned*>(code), h, w, c / 4, gout, gin);
+  else
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, act, h, w, c / 4, gout, gin);
   ST_LAUNCH_RET();
 }
 

@@ -20,8 +20,8 @@ int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* 
 bool st_winograd43_fused_enabled(int h, int w, int cout);
 int st_winograd43_pack(const float* u_prk, int rows, int k, float* u_packed, hipStream_t st);
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
-                        const float* mask, int relu, float* out, float* pool_out, hipStream_t st);
-int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, hipStream_t st);
+                        const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code, hipStream_t st);
+int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, hipStream_t st);
 
 int st_split_planes(const float* x, size_t n, void* planes, hipStream_t s);
 int st_gemm_nt_batched_split(const void* A, int a_pre, size_t a_plane_stride, int lda, long long strideA,

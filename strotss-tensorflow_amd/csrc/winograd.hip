@@ -238,9 +238,9 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
 
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* Upacked,
                           const float* bias, int cout, const float* mask, int relu, float* out, float* pool_out,
-                          void* workspace, size_t workspace_bytes, hipStream_t st) {
+                          unsigned char* pool_code, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (Upacked && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout))      // everything on chip, no workspace
-    return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, st);
+    return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, st);
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const size_t T = (size_t)TH * TW;
   Workspace ws(workspace, workspace_bytes);
@@ -334,22 +334,23 @@ size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout,
 }
 
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok, const float* u_packed,
-                                 const float* bias, int cout, int tile_m, float* out, float* pool_out, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 const float* bias, int cout, int tile_m, float* out, float* pool_out,
+                                 unsigned char* pool_code, void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(in && u_pok && bias && out && workspace && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   ST_CHECK_ARG(!pool_out || (h >= 2 && w >= 2), STROTSS_EINVAL);
+  ST_CHECK_ARG(!pool_code || pool_out, STROTSS_EINVAL);
   const bool fused = tile_m == 4 && u_packed && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout);
   int rc;
   if (tile_m == 4)
-    rc = winograd43_run(in, h, w, cin, u_pok, u_packed, bias, cout, nullptr, 1, out, pool_out, workspace,
+    rc = winograd43_run(in, h, w, cin, u_pok, u_packed, bias, cout, nullptr, 1, out, pool_out, pool_code, workspace,
                         workspace_bytes, (hipStream_t)stream);
   else
     rc = winograd_run(in, h, w, cin, u_pok, bias, cout, nullptr, 1, out, workspace, workspace_bytes,
                       (hipStream_t)stream);
   if (rc != 0 || !pool_out || fused) return rc;           // the fused kernel pooled in its epilogue
-  return st_maxpool2_fwd(out, h, w, cout, pool_out, (hipStream_t)stream);
+  return st_maxpool2_fwd(out, h, w, cout, pool_out, pool_code, (hipStream_t)stream);
 }
 
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
@@ -359,7 +360,7 @@ int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, co
   ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   if (tile_m == 4)
-    return winograd43_run(gout, h, w, cout, u_pik, u_packed, nullptr, cin, act_in, 0, gin, nullptr, workspace, workspace_bytes,
+    return winograd43_run(gout, h, w, cout, u_pik, u_packed, nullptr, cin, act_in, 0, gin, nullptr, nullptr, workspace, workspace_bytes,
                           (hipStream_t)stream);
   return winograd_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
                       (hipStream_t)stream);

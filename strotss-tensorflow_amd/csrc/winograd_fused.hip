@@ -87,7 +87,8 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
                                                                 const float* __restrict__ U, int Cout,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ mask, int relu,
-                                                                float* __restrict__ out, float* __restrict__ pool, int RW, int NG, int nitems) {
+                                                                float* __restrict__ out, float* __restrict__ pool, unsigned char* __restrict__ pool_code, int RW,
+                                                                int NG, int nitems) {
   __shared__ __attribute__((aligned(16))) float lds[F_LDS_FLOATS];
   float* const Vb = lds;                            // V[2]
   float* const Rb = lds + 2 * F_V;                  // raw[2]
@@ -385,9 +386,16 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
 #pragma unroll
               for (int pc = 0; pc < 2; ++pc)
                 if (py0 + pr < PH && px0 + pc < PW) {
-                  const float m0 = fmaxf(Y[i][2 * pr][2 * pc], Y[i][2 * pr][2 * pc + 1]);
-                  const float m1 = fmaxf(Y[i][2 * pr + 1][2 * pc], Y[i][2 * pr + 1][2 * pc + 1]);
-                  pool[((size_t)(py0 + pr) * PW + px0 + pc) * Cout + co] = fmaxf(fmaxf(m0, m1), lo);
+                  const float v4[4] = {Y[i][2 * pr][2 * pc], Y[i][2 * pr][2 * pc + 1], Y[i][2 * pr + 1][2 * pc],
+                                       Y[i][2 * pr + 1][2 * pc + 1]};
+                  int best = 0;
+                  float bv = v4[0];
+#pragma unroll
+                  for (int q4 = 1; q4 < 4; ++q4)
+                    if (v4[q4] > bv) { bv = v4[q4]; best = q4; }
+                  const size_t po = ((size_t)(py0 + pr) * PW + px0 + pc) * Cout + co;
+                  pool[po] = fmaxf(bv, lo);
+                  if (pool_code) pool_code[po] = (unsigned char)(bv > 0.f ? best : 4);   // argmax code of maxpool2_fwd
                 }
           }
         }
@@ -438,7 +446,8 @@ bool st_winograd43_fused_enabled(int h, int w, int cout) {
 }
 
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
-                        const float* mask, int relu, float* out, float* pool_out, hipStream_t st) {
+                        const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code,
+                        hipStream_t st) {
   if (cin % 32 != 0 || cout % 32 != 0) return STROTSS_EALIGN;
   if ((size_t)h * w * cin >= ((size_t)1 << 30) || (size_t)h * w * cout >= ((size_t)1 << 30)) return STROTSS_EALIGN;
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
@@ -456,9 +465,9 @@ int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, 
   while (grid > 8 && grid / 2 >= nitems) grid /= 2;
   if (mask)
     hipLaunchKernelGGL(winograd43_fused_kernel<true>, dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, cin, U, cout,
-                       bias, mask, relu, out, pool_out, RW, NG, nitems);
+                       bias, mask, relu, out, pool_out, pool_code, RW, NG, nitems);
   else
     hipLaunchKernelGGL(winograd43_fused_kernel<false>, dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, cin, U, cout,
-                       bias, mask, relu, out, pool_out, RW, NG, nitems);
+                       bias, mask, relu, out, pool_out, pool_code, RW, NG, nitems);
   ST_LAUNCH_RET();
 }

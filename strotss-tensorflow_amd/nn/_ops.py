@@ -127,7 +127,7 @@ def winograd_packed(u: torch.Tensor):
     return up
 
 
-def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None):
+def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None):
     """u_pok: (16, cout, cin) -> F(2x2,3x3), (36, cout, cin) -> F(4x4,3x3).  pool_out: (1, h//2, w//2, cout) buffer
     that also receives the 2x2/2 max-pool of the result."""
     require(x, "conv input"); h, w, cin = hwc(x)
@@ -137,7 +137,7 @@ def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None):
     m = _tile_m(u_pok)
     ws, nb = _wino_ws(h, w, cin, cout, m, x.device)
     check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(winograd_packed(u_pok)), ptr(bias),
-                                                  cout, m, ptr(out), ptr(pool_out), ptr(ws), nb, stream_ptr()),
+                                                  cout, m, ptr(out), ptr(pool_out), ptr(pool_code), ptr(ws), nb, stream_ptr()),
           "conv3x3_winograd_fwd")
     return out
 
@@ -167,19 +167,21 @@ def winograd_weights(g: torch.Tensor, tile_m: int = 2) -> torch.Tensor:
     return u.reshape(G.shape[0] ** 2, g.shape[0], g.shape[1]).float().contiguous()
 
 
-def maxpool2_fwd(x, out=None):
+def maxpool2_fwd(x, out=None, code=None):
+    """code: optional (1, h//2, w//2, c) uint8 buffer receiving the argmax codes for maxpool2_bwd."""
     require(x, "pool input"); h, w, c = hwc(x)
     if out is None:
         out = torch.empty((1, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
-    check(_hip.lib().strotss_maxpool2_fwd(ptr(x), h, w, c, ptr(out), stream_ptr()), "maxpool2_fwd")
+    check(_hip.lib().strotss_maxpool2_fwd(ptr(x), h, w, c, ptr(out), ptr(code), stream_ptr()), "maxpool2_fwd")
     return out
 
 
-def maxpool2_bwd(act, gout, out=None):
+def maxpool2_bwd(act, gout, out=None, code=None):
+    """With `code` (from the forward pass) the activations are not read."""
     require(act, "pool act"); require(gout, "pool grad"); h, w, c = hwc(act)
     if out is None:
         out = torch.empty_like(act)
-    check(_hip.lib().strotss_maxpool2_bwd(ptr(act), h, w, c, ptr(gout), ptr(out), stream_ptr()),
+    check(_hip.lib().strotss_maxpool2_bwd(ptr(act), h, w, c, ptr(gout), ptr(out), ptr(code), stream_ptr()),
           "maxpool2_bwd")
     return out
 

@@ -195,6 +195,8 @@ class VGGTrunk:
         self.wtile = [winograd_tile(int(a.shape[1]), int(a.shape[2]), L["cin"]) if "u_fwd" in L else 0
                       for L, a in zip(params.layers, self.acts)]
         if with_grad:
+            # argmax codes of the pools (1 byte per pooled element): the backward pass reads them, not the activations
+            self.pool_codes = [torch.empty(p.shape, dtype=torch.uint8, device=dev) for p in self.pools]
             self.grads = [torch.empty_like(a) for a in self.acts]
             self.gpools = [torch.empty_like(p) for p in self.pools]
             self.gimg = torch.empty((1, h, w, 3), dtype=torch.float32, device=dev)
@@ -211,7 +213,8 @@ class VGGTrunk:
         for si, step in enumerate(self.plan):
             if step[0] == 'pool':
                 if step[1] not in pooled:
-                    _ops.maxpool2_fwd(self.acts[step[2]], out=self.pools[step[1]])
+                    _ops.maxpool2_fwd(self.acts[step[2]], out=self.pools[step[1]],
+                                      code=self.pool_codes[step[1]] if self.with_grad else None)
             else:
                 _, li, src = step
                 L = P.layers[li]
@@ -220,12 +223,13 @@ class VGGTrunk:
                     _ops.conv3x3_c3_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li], mean=P.mean, std=P.std)
                 elif self.wtile[li]:
                     nxt = self.plan[si + 1] if si + 1 < len(self.plan) else None
-                    pool_out = None
+                    pool_out = pool_code = None
                     if nxt is not None and nxt[0] == 'pool' and nxt[2] == li:     # the pool of this layer rides along
                         pool_out = self.pools[nxt[1]]
+                        pool_code = self.pool_codes[nxt[1]] if self.with_grad else None
                         pooled.add(nxt[1])
                     _ops.conv3x3_winograd_fwd(x, L["u_fwd"][self.wtile[li]], L["bias"], out=self.acts[li],
-                                              pool_out=pool_out)
+                                              pool_out=pool_out, pool_code=pool_code)
                 else:
                     _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
         return [self.acts[i] for i in self.taps]
@@ -243,7 +247,8 @@ class VGGTrunk:
         for step in reversed(self.plan):
             if step[0] == 'pool':
                 _, pi, src_layer = step
-                _ops.maxpool2_bwd(self.acts[src_layer], self.gpools[pi], out=self.grads[src_layer])
+                _ops.maxpool2_bwd(self.acts[src_layer], self.gpools[pi], out=self.grads[src_layer],
+                                  code=self.pool_codes[pi])
                 if src_layer in tapped:
                     scatter(src_layer)
             else:

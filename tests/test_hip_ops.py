@@ -145,8 +145,10 @@ def test_conv_winograd_fwd_and_dgrad(ops, cfg, tile_m):
     assert rel_err(got, y.detach().numpy()) < tol
     if h >= 2 and w >= 2:                  # the pooled copy riding along (fused epilogue or a pooling launch)
         pooled = torch.full((1, h // 2, w // 2, cout), -1.0, device="cuda")
-        got2 = ops.conv3x3_winograd_fwd(dev(x), u_f, dev(b), pool_out=pooled)
-        assert torch.equal(pooled, ops.maxpool2_fwd(got2))
+        code = torch.full((1, h // 2, w // 2, cout), 9, dtype=torch.uint8, device="cuda")
+        got2 = ops.conv3x3_winograd_fwd(dev(x), u_f, dev(b), pool_out=pooled, pool_code=code)
+        code_ref = torch.empty_like(code)
+        assert torch.equal(pooled, ops.maxpool2_fwd(got2, code=code_ref)) and torch.equal(code, code_ref)
     gy = torch.randn(1, h, w, cout, generator=g, dtype=torch.float64)
     ypre = _conv_ref(xin, wt, b, relu=False)
     (ypre * gy).sum().backward()
@@ -206,6 +208,12 @@ def test_maxpool(ops, hwc):
     # routed to the first max and masked by act > 0 (all-zero windows carry no gradient)
     ref = (xin.grad * (x > 0)).numpy()
     assert np.abs(got - ref).max() < 1e-6
+    # the same through the forward pass's argmax codes (one byte per pooled element; the activations are not read)
+    code = torch.empty((1, h // 2, w // 2, c), dtype=torch.uint8, device="cuda")
+    assert np.array_equal(ops.maxpool2_fwd(dev(x), code=code).cpu().numpy(), y.detach().numpy().astype(np.float32))
+    assert int(code.max()) <= 4
+    got2 = ops.maxpool2_bwd(dev(x), dev(gy), code=code).cpu().numpy()
+    assert np.array_equal(got2, got)
 
 
 # ------------------------------------------------------------------ hypercolumns

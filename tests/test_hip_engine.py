@@ -363,3 +363,17 @@ def test_cli_config1_reference_images(tmp_path):
     assert seen and seen[-1][0] == 50 and np.isfinite(seen[-1][1])
     with Image.open(out) as im:
         assert im.format == "JPEG" and im.size == (256, 170)
+
+
+def test_step_parity_with_the_fused_winograd_kernel_forced():
+    """The size policy keeps the fused F(4x4,3x3) kernel away from the small images the float64 oracle can check; force it
+    (STROTSS_WINO_FUSED=2, read once per process) and repeat the step-level oracle parity tests in a child process."""
+    import subprocess, sys
+    if os.environ.get("STROTSS_WINO_FUSED") == "2":
+        pytest.skip("already inside the forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_engine.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "matches_oracle or resynchronised"], env=dict(os.environ, STROTSS_WINO_FUSED="2"), cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

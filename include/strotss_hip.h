@@ -89,8 +89,16 @@ int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const fl
  * u_packed (tile_m = 4 only, may be NULL): the same weights in the MFMA-fragment order written by
  * strotss_conv3x3_winograd_pack (same number of floats).  With it, layers the three-kernel form would run bound
  * by its transform traffic (few output channels, many tiles) run as ONE persistent kernel that keeps the
- * transforms and the 36 GEMMs on chip (csrc/winograd_fused.hip); the workspace is then not touched. */
+ * transforms and the 36 GEMMs on chip (csrc/winograd_fused.hip); the workspace is then not touched.
+ * u_x3 (tile_m = 4 only, may be NULL): the same weights as "x3 panels" written by strotss_conv3x3_winograd_x3pack
+ * (strotss_conv3x3_winograd_x3_bytes bytes).  With it, the 36 GEMMs of the three-kernel form run on the bf16 MFMA by
+ * EXACT 3-way operand splitting (every f32 value = h + m + l in bf16, six exact partial products, f32 accumulation:
+ * f32-class results at 6/16 of the f32-MFMA cost, csrc/mfma_x3.h); NULL or STROTSS_X3=0 keeps them on the f32 MFMA. */
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m);
+/* u_prk: (36, rows, k) -> x3 panels: per position p, element (r, c) split into bf16 planes h, m, l at
+ * ((p * (k/32) + c/32) * 3 + plane) * rows * 32 + r * 32 + c % 32   (bf16 units).  k % 32 == 0. */
+size_t strotss_conv3x3_winograd_x3_bytes(int rows, int k);
+int strotss_conv3x3_winograd_x3pack(const float* u_prk, int rows, int k, void* u_x3, void* stream);
 /* u_prk: (36, rows, k) -> u_packed[p][rows/32][k/8][2][32][4]: element (p, r, c) at
  * ((((p * (rows/32) + r/32) * (k/8) + c/8) * 2 + (c%8)/4) * 32 + r%32) * 4 + c%4.  rows % 32 == 0, k % 8 == 0. */
 int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_packed, void* stream);
@@ -98,11 +106,11 @@ int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_
  * from the registers of the fused kernel's epilogue where that kernel runs, by a pooling launch otherwise;
  * pool_code (may be NULL, needs pool_out): the argmax codes of that pooling, see strotss_maxpool2_fwd. */
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok,
-                                 const float* u_packed, const float* bias, int cout, int tile_m, float* out,
+                                 const float* u_packed, const void* u_x3, const float* bias, int cout, int tile_m, float* out,
                                  float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
                                  void* stream);
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
-                                   const float* u_packed, int cin, int tile_m, const float* act_in, float* gin,
+                                   const float* u_packed, const void* u_x3, int cin, int tile_m, const float* act_in, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream);
 /* 2x2/2 VALID max-pool: out(h/2, w/2, c).  code (may be NULL): (h/2, w/2, c) bytes, the index 0..3 of the FIRST
  * max of each window in scan order (0,0),(0,1),(1,0),(1,1), or 4 when that max is not positive. */

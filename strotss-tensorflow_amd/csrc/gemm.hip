@@ -4,7 +4,7 @@
 
 #include "internal.h"
 #include "mfma_pipe.h"
-#include "mfma_split.h"
+#include "mfma_x3.h"
 
 namespace {
 
@@ -214,68 +214,6 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kc_pipe_kernel(const float* __re
   epi.finish(lds, local);
 }
 
-// ---- f32 GEMM on the bf16 MFMA by exact 3-way splitting (mfma_split.h) ---------------------------
-// x -> three bf16 planes (h, m, l), elementwise; used to pre-split frozen B operands.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, size_t n4,
-                                                           __bf16* __restrict__ planes, size_t plane_stride) {
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
-    const Split3 s = split3(reinterpret_cast<const f32x4*>(x)[e]);
-    *reinterpret_cast<bf16x4*>(planes + 4 * e) = s.h;
-    *reinterpret_cast<bf16x4*>(planes + plane_stride + 4 * e) = s.m;
-    *reinterpret_cast<bf16x4*>(planes + 2 * plane_stride + 4 * e) = s.l;
-  }
-}
-
-
-
-template <int R> struct SplitACfg { static constexpr int RPP = R; };   // f32 staging: 8 lanes per row
-
-// B (frozen weights) is pre-split into bf16 planes.  A is either f32 (split at the LDS store, APRE = false)
-// or three bf16 planes written by winograd_in_kernel<true> (APRE = true).
-template <class Cfg, class Epi>
-__global__ __launch_bounds__(Cfg::NT) void gemm_split_kernel(const void* __restrict__ Av, size_t a_plane_stride,
-                                                         int lda, int M, long long strideA,
-                                                         const __bf16* __restrict__ Bp, size_t b_plane_stride,
-                                                         int ldb, int N, long long strideB, int K, Epi epi) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[Cfg::LDS_BYTES];
-  // 1-D launch, XCD-aware tile order: N-tile fastest, then M-tile, then batch
-  const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
-  const unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const unsigned bz = tile / (gx * gy), rem = tile - bz * (gx * gy);
-  Bp += (long long)bz * strideB;
-  epi.set_batch(bz);
-  const int m0 = (rem / gx) * Cfg::BM, n0 = (rem % gx) * Cfg::BN;
-  auto make_a = [&]() {
-    if constexpr (Cfg::APRE)
-      return PlaneRowLoader<Cfg::NA, Cfg::RPP_PRE>(reinterpret_cast<const __bf16*>(Av) + (long long)bz * strideA,
-                                                   a_plane_stride, lda, m0, M, K);
-    else
-      return RowMajorLoader<SplitACfg<Cfg::RPP_F32>, Cfg::NA>(
-          reinterpret_cast<const float*>(Av) + (long long)bz * strideA, lda, m0, M, K);
-  };
-  auto la = make_a();
-  PlaneRowLoader<Cfg::NB, Cfg::RPP_PRE> lb(Bp, b_plane_stride, ldb, n0, N, K);
-  f32x16 acc[Cfg::TM][Cfg::TN];
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  split_mainloop<Cfg>(lds, K >> 5, la, lb, acc);
-  PipeAccMap<Cfg> map;
-  float local = 0.f;
-#pragma unroll
-  for (int im = 0; im < Cfg::TM; ++im)
-#pragma unroll
-    for (int in = 0; in < Cfg::TN; ++in)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
-  __syncthreads();
-  epi.finish(reinterpret_cast<float*>(lds), local);
-}
-
 static int gemm_waves() {
   static int v = -1;
   if (v < 0) {
@@ -393,40 +331,23 @@ int st_gemm_nt_batched(const float* A, int lda, long long strideA, const float* 
   return launch_pipe<64, 64>(A, lda, M, strideA, B, ldb, N, strideB, K, batch, e, s);
 }
 
-int st_split_planes(const float* x, size_t n, void* planes, hipStream_t s) {
-  const size_t n4 = n / 4;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)min((size_t)4096, (n4 + 255) / 256)), dim3(256), 0, s, x, n4,
-                     (__bf16*)planes, n);
+// ---- f32 GEMM cores on the bf16 MFMA by exact 3-way operand splitting (mfma_x3.h) -----------------
+// x (batch, rows, ld) f32 row-major, first K columns -> x3 panels (batch stride 3 * rows * K bf16).
+int st_x3_split_rows(const float* x, int rows, int ld, int K, long long stride_in, void* panels, int batch,
+                     hipStream_t s) {
+  const size_t total = (size_t)rows * (K >> 2);
+  hipLaunchKernelGGL(x3_split_rows_kernel, dim3((unsigned)min((size_t)2048, (total + 255) / 256), batch), dim3(256), 0, s,
+                     x, rows, ld, K, stride_in, (__bf16*)panels, (long long)3 * rows * K);
   ST_LAUNCH_RET();
 }
 
-// As st_gemm_nt_batched on the bf16 MFMA (mfma_split.h).  B: three pre-split bf16 planes.  A: f32 (a_pre = 0,
-// split in the kernel) or three bf16 planes (a_pre = 1).  nprod = 6 | 9 partial products.
-template <bool APRE, int NP>
-static int launch_split(const void* A, size_t a_plane_stride, int lda, long long strideA, const void* Bp,
-                        size_t b_plane_stride, int ldb, long long strideB, EpiScaleStore e, int M, int N, int K,
-                        int batch, hipStream_t s) {
-  dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
-  static int w8 = -1;
-  if (w8 < 0) { const char* ev = getenv("STROTSS_SPLIT_WAVES"); w8 = (ev && atoi(ev) == 8) ? 1 : 0; }
-  if (w8) {
-    using Cfg = SplitCfg<128, 128, APRE, true, NP, 2, 4>;
-    hipLaunchKernelGGL((gemm_split_kernel<Cfg, EpiScaleStore>), grid, dim3(Cfg::NT), 0, s, A, a_plane_stride, lda, M,
-                       strideA, (const __bf16*)Bp, b_plane_stride, ldb, N, strideB, K, e);
-  } else {
-    using Cfg = SplitCfg<128, 128, APRE, true, NP>;
-    hipLaunchKernelGGL((gemm_split_kernel<Cfg, EpiScaleStore>), grid, dim3(Cfg::NT), 0, s, A, a_plane_stride, lda, M,
-                       strideA, (const __bf16*)Bp, b_plane_stride, ldb, N, strideB, K, e);
-  }
-  ST_LAUNCH_RET();
-}
-int st_gemm_nt_batched_split(const void* A, int a_pre, size_t a_plane_stride, int lda, long long strideA,
-                             const void* Bp, size_t b_plane_stride, int ldb, long long strideB, float* C, int ldc,
-                             long long strideC, int M, int N, int K, int batch, int nprod, hipStream_t s) {
+// C[z] (M x N, ldc) = A[z] B[z]^T, both operands as x3 panels of K columns (K % 32 == 0).
+int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
+                       int batch, hipStream_t s) {
+  using Cfg = X3Cfg<128, 128>;
   EpiScaleStore e{C, ldc, M, N, 1.0f, strideC};
-  if (a_pre)
-    return nprod == 9 ? launch_split<true, 9>(A, a_plane_stride, lda, strideA, Bp, b_plane_stride, ldb, strideB, e, M, N, K, batch, s)
-                      : launch_split<true, 6>(A, a_plane_stride, lda, strideA, Bp, b_plane_stride, ldb, strideB, e, M, N, K, batch, s);
-  return nprod == 9 ? launch_split<false, 9>(A, a_plane_stride, lda, strideA, Bp, b_plane_stride, ldb, strideB, e, M, N, K, batch, s)
-                    : launch_split<false, 6>(A, a_plane_stride, lda, strideA, Bp, b_plane_stride, ldb, strideB, e, M, N, K, batch, s);
+  dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStore>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
+                     (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e);
+  ST_LAUNCH_RET();
 }

@@ -23,10 +23,11 @@ int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, 
                         const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code, hipStream_t st);
 int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, hipStream_t st);
 
-int st_split_planes(const float* x, size_t n, void* planes, hipStream_t s);
-int st_gemm_nt_batched_split(const void* A, int a_pre, size_t a_plane_stride, int lda, long long strideA,
-                             const void* Bp, size_t b_plane_stride, int ldb, long long strideB, float* C, int ldc,
-                             long long strideC, int M, int N, int K, int batch, int nprod, hipStream_t s);
+// f32 GEMM cores on the bf16 MFMA (mfma_x3.h): operands as "x3 panels" (3 * rows * K bf16 per batch entry)
+int st_x3_split_rows(const float* x, int rows, int ld, int K, long long stride_in, void* panels, int batch,
+                     hipStream_t s);
+int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
+                       int batch, hipStream_t s);
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

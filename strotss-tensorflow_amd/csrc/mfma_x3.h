@@ -1,0 +1,241 @@
+// f32 GEMM cores on the bf16 MFMA by exact 3-way operand splitting ("bf16x3 operands, 6 products").
+//
+// gfx950 runs v_mfma_f32_32x32x2_f32 at 1/16 of the bf16 MFMA rate.  Every f32 value splits EXACTLY into
+// three bf16 values, x = h + m + l (h = bf16(x), m = bf16(x-h), l = bf16(x-h-m): 3 x 8 mantissa bits +
+// signs cover the 24-bit f32 mantissa), so an f32 product is
+//     x*y = hh + (hm + mh) + (hl + mm + lh) + [ml + lm + ll],
+// where each partial product is EXACT in f32 (8 x 8 bits) and the bracket is below 2^-24 relative.  The
+// six leading partial products on v_mfma_f32_32x32x16_bf16 with f32 accumulation give f32-class accuracy
+// (tests/test_hip_ops.py::test_x3_gemm_accuracy: error against fp64 not above the native f32-MFMA path)
+// at 6/16 of the f32-MFMA cost.  This is NOT a reduced-precision mode: inputs, outputs and accumulators
+// are f32; the split is a change of number representation, not a rounding.
+//
+// Operand format ("x3 panels"): both operands arrive PRE-SPLIT from their producers (the Winograd input
+// transform, the weight pack, the feature-row pass), K-blocked so that what a workgroup stages per K-step
+// is contiguous:
+//     element (kb, plane, row, k)  at  base + ((kb * 3 + plane) * rows + row) * 32 + k      (bf16)
+// with kb = K-block of 32, plane in {h, m, l}.  A 128-row tile of one plane and one K-block is 8 KiB of
+// consecutive bytes: every staging load instruction of a wave reads 1 KiB contiguous, there is no split
+// arithmetic, no zero-select and no address arithmetic in the main loop (rows past the operand's end are
+// clamped at set-up; their products land in accumulator rows the epilogue masks).
+//
+// Block tile 128x128, 256 threads = 2x2 waves (64x64 per wave as 32x32 MFMA tiles), K-step 32 = 2 MFMA
+// k-chunks x 6 products x 4 tiles = 48 MFMAs per wave (see the main loop below).
+#pragma once
+#include <type_traits>
+
+#include "mfma_pipe.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Split3 { bf16x4 h, m, l; };
+__device__ __forceinline__ Split3 split3(const f32x4 x) {
+  Split3 s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const __bf16 h = (__bf16)x[k];
+    const float r1 = x[k] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    s.h[k] = h; s.m[k] = m; s.l[k] = (__bf16)r2;
+  }
+  return s;
+}
+
+// x3 panel addressing (elements): see the header comment.
+__host__ __device__ __forceinline__ size_t x3_panel_elems(size_t rows, size_t K) { return 3 * rows * K; }
+// Stores the split of 4 consecutive k (k0 % 4 == 0) of one row.
+__device__ __forceinline__ void x3_store4(__bf16* base, size_t rows, size_t row, int k0, const f32x4 v) {
+  const Split3 s = split3(v);
+  const size_t o = ((size_t)(k0 >> 5) * 3 * rows + row) * 32 + (k0 & 31);
+  *reinterpret_cast<bf16x4*>(base + o) = s.h;
+  *reinterpret_cast<bf16x4*>(base + o + rows * 32) = s.m;
+  *reinterpret_cast<bf16x4*>(base + o + 2 * rows * 32) = s.l;
+}
+
+// Main loop: operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4), three-stage ring.
+// LDS stage = 6 images (A h,m,l; B h,m,l) of [128 rows][64 B] (one K-block of 32 bf16 per row), UNPADDED
+// because an LDS-DMA wave instruction writes 1 KiB linearly (16 rows); bank conflicts of the fragment reads
+// are removed by an XOR swizzle of the four 16-byte slots of a row, slot' = slot ^ ((row >> 2) & 3), applied
+// on the SOURCE address of the DMA and on the ds_read address (same involution on both sides).
+// Per K-step s: MFMAs on stage s % 3, the DMA of tile s+2 issued between the MFMAs of the first k-chunk into
+// stage (s+2) % 3 (free since the barrier of step s-1), one `s_waitcnt vmcnt(12)` (tile s+1 landed, tile
+// s+2 stays in flight ACROSS the barrier) + lgkmcnt(0) + raw s_barrier in the second k-chunk, then the first
+// fragments of tile s+1.  No staging registers, no ds_write, no VALU in the loop besides 4 address adds.
+template <int BM_, int BN_>
+struct X3Cfg {
+  static_assert(BM_ == 128 && BN_ == 128, "x3 main loop is written for 128 x 128 tiles");
+  static constexpr int BM = BM_, BN = BN_, WM = 2, WN = 2, NT = 256, TM = 2, TN = 2;
+  static constexpr int PL = 128 * 64;                    // bytes of one plane image
+  static constexpr int STAGE = 6 * PL;                   // 48 KiB
+  static constexpr int LDS_BYTES = 3 * STAGE;            // 144 KiB
+};
+
+#define X3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+struct X3Operand {          // one x3 panel operand as seen by one wave's DMA lanes
+  const char* base;          // batch base, bytes
+  unsigned off[2];           // byte offset of this lane's 16-byte source chunk within a plane panel, 2 row groups
+  unsigned plane;            // bytes per plane panel (rows * 64)
+  unsigned cur;              // byte offset of the current K-block (3 planes per K-block)
+  __device__ __forceinline__ X3Operand(const __bf16* p, int rows, int row0) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    base = reinterpret_cast<const char*>(p);
+    plane = (unsigned)rows * 64u;
+    cur = 0;
+    const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // source-side swizzle: (row >> 2) & 3 == (lane >> 4) & 3
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int row = min(row0 + (2 * wave + g) * 16 + (lane >> 2), rows - 1);
+      off[g] = (unsigned)row * 64u + (unsigned)chunk * 16u;
+    }
+  }
+  __device__ __forceinline__ void dma(int pl, int g, unsigned char* lds_dst) const {
+    const char* src = base + (size_t)(cur + pl * plane) + off[g];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+  }
+  __device__ __forceinline__ void advance() { cur += 3 * plane; }
+};
+
+template <class Cfg>
+__device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Operand& oa, X3Operand& ob,
+                                             f32x16 (&acc)[2][2]) {
+  constexpr int PL = Cfg::PL, STAGE = Cfg::STAGE;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+  // DMA piece j of a K-step (12 per wave): operand j / 6, plane (j % 6) / 2, row group j % 2
+  auto dma_piece = [&](int j, unsigned char* stage) {
+    const int op = j / 6, pl = (j % 6) / 2, g = j % 2;
+    unsigned char* dst = stage + (op * 3 + pl) * PL + (2 * wave + g) * 1024;
+    if (op == 0) oa.dma(pl, g, dst); else ob.dma(pl, g, dst);
+  };
+  auto dma_tile = [&](unsigned char* stage) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) dma_piece(j, stage);
+    oa.advance(); ob.advance();
+  };
+  // fragment read offsets within a stage: row-major 64-byte rows, slot = (2 kc + hh) ^ ((row >> 2) & 3)
+  const int f = (l31 >> 2) & 3;
+  const int a_rd = (wm * 64 + l31) * 64 + ((hh ^ f) << 4);              // kc = 0; kc = 1 is this ^ 32
+  const int b_rd = 3 * PL + (wn * 64 + l31) * 64 + ((hh ^ f) << 4);
+  bf16x8 fa[2][3][2], fb[2][3][2];
+  auto read_frags = [&](const unsigned char* stage, int kc, int slot) {
+    const unsigned char* pa = stage + (a_rd ^ (kc << 5));
+    const unsigned char* pb = stage + (b_rd ^ (kc << 5));
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[slot][p][i] = *reinterpret_cast<const bf16x8*>(pa + p * PL + i * 2048);
+        fb[slot][p][i] = *reinterpret_cast<const bf16x8*>(pb + p * PL + i * 2048);
+      }
+    }
+  };
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};     // partial products (A plane, B plane), smallest terms first
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+  unsigned char* s_cur = lds;
+  unsigned char* s_nxt = lds + STAGE;
+  unsigned char* s_nn = lds + 2 * STAGE;
+  dma_tile(s_cur);
+  if (steps > 1) { dma_tile(s_nxt); X3_WAIT_VM(12); } else { X3_WAIT_VM(0); }
+  __builtin_amdgcn_s_barrier();
+  read_frags(s_cur, 0, 0);
+
+  // MODE 2: tile s+2 exists (DMA it, leave it in flight); 1: tile s+1 is the last (wait for it); 0: last step
+  auto kstep = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        if (c == 0 && q == 1) {          // second k-chunk's fragments: behind the first product group
+          __builtin_amdgcn_sched_barrier(0);
+          read_frags(s_cur, 1, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+#pragma unroll
+          for (int in_ = 0; in_ < 2; ++in_)
+            acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][PA[q]][im], fb[c][PB[q]][in_], acc[im][in_], 0, 0, 0);
+          if (MODE == 2 && c == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(2 * q + im, s_nn);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (c == 1 && q == 0 && MODE != 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (MODE == 2) X3_WAIT_VM(12); else X3_WAIT_VM(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          read_frags(s_nxt, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (MODE == 2) { oa.advance(); ob.advance(); }
+    unsigned char* tmp = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = tmp;
+  };
+  int s = 0;
+  for (; s + 2 < steps; ++s) kstep(std::integral_constant<int, 2>{});
+  if (steps > 1) kstep(std::integral_constant<int, 1>{});
+  kstep(std::integral_constant<int, 0>{});
+}
+
+template <class Cfg, class Epi>
+__global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restrict__ A, int M, long long strideA,
+                                                           const __bf16* __restrict__ B, int N, long long strideB,
+                                                           int K, Epi epi) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDS_BYTES];
+  const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
+  const unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned bz = tile / (gx * gy), rem = tile - bz * (gx * gy);
+  epi.set_batch(bz);
+  const int m0 = (rem / gx) * Cfg::BM, n0 = (rem % gx) * Cfg::BN;
+  X3Operand oa(A + (long long)bz * strideA, M, m0);
+  X3Operand ob(B + (long long)bz * strideB, N, n0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  x3_mainloop<Cfg>(lds, K >> 5, oa, ob, acc);
+  PipeAccMap<Cfg> map;
+  float local = 0.f;
+#pragma unroll
+  for (int im = 0; im < 2; ++im)
+#pragma unroll
+    for (int in = 0; in < 2; ++in)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
+  __syncthreads();
+  epi.finish(reinterpret_cast<float*>(lds), local);
+}
+
+// Row-major f32 (rows x ld, K <= ld columns used, K % 32 == 0) -> x3 panels, batched over blockIdx.y.
+// Lane order: 8 lanes cover one row's 32 k (128 B read), consecutive rows follow: 512 contiguous bytes per plane
+// and wave store.
+static __global__ __launch_bounds__(256) void x3_split_rows_kernel(const float* __restrict__ x, int rows, int ld, int K,
+                                                            long long stride_in, __bf16* __restrict__ out,
+                                                            long long stride_out) {
+  x += (long long)blockIdx.y * stride_in;
+  out += (long long)blockIdx.y * stride_out;
+  const size_t total = (size_t)rows * (K >> 2);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int k4 = (int)(e & 7);
+    const size_t rr = e >> 3;
+    const int row = (int)(rr % rows), kb = (int)(rr / rows);
+    const int k0 = kb * 32 + k4 * 4;
+    x3_store4(out, rows, row, k0, *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + k0));
+  }
+}
+

@@ -12,12 +12,11 @@
 #include <stdlib.h>
 
 #include "internal.h"
-#include "mfma_split.h"
+#include "mfma_x3.h"
 
 namespace {
 
 // V: (16, T, C) with T = ceil(H/2)*ceil(W/2); tile (ty,tx) reads input rows 2ty-1..2ty+2, cols 2tx-1..2tx+2
-template <bool SPLIT>
 __global__ __launch_bounds__(256) void winograd_in_kernel(const float* __restrict__ in, int H, int W, int C4,
                                                           int TH, int TW, size_t tile0, size_t T,
                                                           float* __restrict__ V) {
@@ -25,20 +24,7 @@ __global__ __launch_bounds__(256) void winograd_in_kernel(const float* __restric
   const size_t total = T * C4;
   const f32x4* src = reinterpret_cast<const f32x4*>(in);
   f32x4* dst = reinterpret_cast<f32x4*>(V);
-  // SPLIT: V is three bf16 planes of (16, T, C) (plane stride 16*T*C elements), see mfma_split.h
-  __bf16* pl = reinterpret_cast<__bf16*>(V);
-  const size_t plane = (size_t)16 * T * C4 * 4;
-  auto put = [&](int pos, size_t tile, int c, const f32x4 v) {
-    const size_t o = ((size_t)pos * T + tile) * C4 + c;
-    if constexpr (SPLIT) {
-      const Split3 s3 = split3(v);
-      *reinterpret_cast<bf16x4*>(pl + 4 * o) = s3.h;
-      *reinterpret_cast<bf16x4*>(pl + plane + 4 * o) = s3.m;
-      *reinterpret_cast<bf16x4*>(pl + 2 * plane + 4 * o) = s3.l;
-    } else {
-      dst[o] = v;
-    }
-  };
+  auto put = [&](int pos, size_t tile, int c, const f32x4 v) { dst[((size_t)pos * T + tile) * C4 + c] = v; };
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int c = (int)(e % C4);
     const size_t tile = e / C4;
@@ -182,6 +168,52 @@ __global__ __launch_bounds__(256) void winograd43_in_kernel(const float* __restr
   }
 }
 
+// The same transform writing V as x3 panels (mfma_x3.h) for the bf16x3 GEMM core: per position p a panel of
+// T rows x C columns.  Lane order: 8 lanes = the 32 channels of one K-block of one tile (128 B read per pixel),
+// 8 consecutive tiles per wave: 512 contiguous bytes per plane, position and wave store.
+__global__ __launch_bounds__(256) void winograd43_in_x3_kernel(const float* __restrict__ in, int H, int W, int C4,
+                                                               int TH, int TW, __bf16* __restrict__ V) {
+  const size_t T = (size_t)TH * TW;
+  const int KB = C4 >> 3;
+  const size_t total = ((T + 7) >> 3) * 64 * KB;
+  const f32x4* src = reinterpret_cast<const f32x4*>(in);
+  const size_t panel = 3 * T * (size_t)C4 * 4;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c8 = (int)(e & 7), tlo = (int)((e >> 3) & 7);
+    const size_t r = e >> 6;
+    const int kb = (int)(r % KB);
+    const size_t tile = (r / KB) * 8 + tlo;
+    if (tile >= T) continue;
+    const int c = kb * 8 + c8;
+    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+    f32x4 d[6][6];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      const int y = 4 * ty - 1 + rr;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int x = 4 * tx - 1 + q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && x >= 0 && x < W) v = src[((size_t)y * W + x) * C4 + c];
+        d[rr][q] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {        // columns: t = B^T d
+      f32x4 col[6] = {d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]};
+      bt6(col);
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) d[rr][q] = col[rr];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {     // rows: V = t B
+      bt6(d[rr]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) x3_store4(V + (size_t)(rr * 6 + q) * panel, T, tile, 4 * c, d[rr][q]);
+    }
+  }
+}
+
 // Y = A^T M A (4x4 outputs per tile);  out = relu(Y + bias)  or  (mask > 0 ? Y : 0)
 __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __restrict__ Mw, int H, int W, int C4,
                                                              int TH, int TW, const float* __restrict__ bias,
@@ -236,22 +268,46 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
   }
 }
 
+// The 36 GEMMs run on the bf16x3 core (mfma_x3.h) where the weights' x3 panels are given and the launch has at least
+// STROTSS_X3_MIN_TILES 128 x 128 output tiles (default 1024 = four rounds of the 256 CUs; measured: with fewer -- idle CUs, half-empty
+// 128-row tiles -- the f32 core with its smaller tiles wins: 512-px scale 2.28 vs 2.41 ms/step).  STROTSS_X3 = 0 keeps every GEMM on the f32 MFMA.
+static bool x3_enabled(size_t T, int cout) {
+  static int on = -1;
+  static long min_tiles = 1024;
+  if (on < 0) {
+    const char* e = getenv("STROTSS_X3"); on = e ? atoi(e) : 1;
+    const char* m = getenv("STROTSS_X3_MIN_TILES"); if (m) min_tiles = atol(m);
+  }
+  return on != 0 && (long)((T + 127) / 128) * ((cout + 127) / 128) * 36 >= min_tiles;
+}
+
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* Upacked,
-                          const float* bias, int cout, const float* mask, int relu, float* out, float* pool_out,
-                          unsigned char* pool_code, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                          const void* Ux3, const float* bias, int cout, const float* mask, int relu, float* out,
+                          float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
+                          hipStream_t st) {
   if (Upacked && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout))      // everything on chip, no workspace
     return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, st);
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const size_t T = (size_t)TH * TW;
+  const bool x3 = Ux3 && cin % 32 == 0 && x3_enabled(T, cout);
   Workspace ws(workspace, workspace_bytes);
-  float* V = ws.take<float>(36 * T * cin);
+  float* V = ws.take<float>(36 * T * cin * 3 / 2);           // f32 V, or its x3 panels (3 bf16 per value)
   float* Mw = ws.take<float>(36 * T * cout);
   if (!ws.ok()) return STROTSS_EINVAL;
-  const size_t tin = T * (cin / 4), tout = T * (cout / 4);
-  hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
-                     h, w, cin / 4, TH, TW, V);
-  const int rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
-                                    (long long)T * cout, (int)T, cout, cin, 36, st);
+  const size_t tout = T * (cout / 4);
+  int rc;
+  if (x3) {
+    const size_t tin = ((T + 7) / 8) * 8 * (cin / 4);
+    hipLaunchKernelGGL(winograd43_in_x3_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
+                       in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V));
+    rc = st_gemm_x3_batched(V, Ux3, Mw, cout, (long long)T * cout, (int)T, cout, cin, 36, st);
+  } else {
+    const size_t tin = T * (cin / 4);
+    hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
+                       h, w, cin / 4, TH, TW, V);
+    rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
+                            (long long)T * cout, (int)T, cout, cin, 36, st);
+  }
   if (rc != 0) return rc;
   hipLaunchKernelGGL(winograd43_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
                      Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out);
@@ -278,40 +334,16 @@ int winograd_run(const float* in, int h, int w, int cin, const float* U, const f
   const size_t T = (size_t)TH * TW;
   const size_t Tc = wino_chunk_tiles(T, cin, cout);
   Workspace ws(workspace, workspace_bytes);
-  float* V = ws.take<float>(16 * Tc * cin * 3 / 2 + 64);      // f32 V, or three bf16 planes (1.5x)
+  float* V = ws.take<float>(16 * Tc * cin);
   float* Mw = ws.take<float>(16 * Tc * cout);
-  unsigned short* Up = ws.take<unsigned short>((size_t)3 * 16 * cout * cin);
   if (!ws.ok()) return STROTSS_EINVAL;
-  // EXPERIMENTAL, off by default: STROTSS_MFMA_SPLIT = 6 | 9 runs the 16 GEMMs on the bf16 MFMA by exact
-  // 3-way splitting (mfma_split.h); STROTSS_MFMA_SPLIT_APRE = 1 also pre-splits V in the input transform.
-  static int split = -1, apre = 0;
-  if (split < 0) {
-    const char* e = getenv("STROTSS_MFMA_SPLIT"); split = e ? atoi(e) : 0;
-    const char* a = getenv("STROTSS_MFMA_SPLIT_APRE"); apre = a ? atoi(a) : 0;
-  }
-  const bool use_split = split && cout % 128 == 0;
-  if (use_split) {
-    const int rc = st_split_planes(U, (size_t)16 * cout * cin, Up, st);
-    if (rc != 0) return rc;
-  }
   for (size_t t0 = 0; t0 < T; t0 += Tc) {
     const size_t tc = (T - t0 < Tc) ? T - t0 : Tc;
     const size_t tin = tc * (cin / 4), tout = tc * (cout / 4);
     const dim3 gin((unsigned)min((size_t)16384, (tin + 255) / 256)), gout((unsigned)min((size_t)16384, (tout + 255) / 256));
-    int rc;
-    if (use_split) {
-      if (apre)
-        hipLaunchKernelGGL(winograd_in_kernel<true>, gin, dim3(256), 0, st, in, h, w, cin / 4, TH, TW, t0, tc, V);
-      else
-        hipLaunchKernelGGL(winograd_in_kernel<false>, gin, dim3(256), 0, st, in, h, w, cin / 4, TH, TW, t0, tc, V);
-      rc = st_gemm_nt_batched_split(V, apre, (size_t)16 * tc * cin, cin, (long long)tc * cin, Up,
-                                    (size_t)16 * cout * cin, cin, (long long)cout * cin, Mw, cout,
-                                    (long long)tc * cout, (int)tc, cout, cin, 16, split, st);
-    } else {
-      hipLaunchKernelGGL(winograd_in_kernel<false>, gin, dim3(256), 0, st, in, h, w, cin / 4, TH, TW, t0, tc, V);
-      rc = st_gemm_nt_batched(V, cin, (long long)tc * cin, U, cin, (long long)cout * cin, Mw, cout,
-                              (long long)tc * cout, (int)tc, cout, cin, 16, st);
-    }
+    hipLaunchKernelGGL(winograd_in_kernel, gin, dim3(256), 0, st, in, h, w, cin / 4, TH, TW, t0, tc, V);
+    const int rc = st_gemm_nt_batched(V, cin, (long long)tc * cin, U, cin, (long long)cout * cin, Mw, cout,
+                                      (long long)tc * cout, (int)tc, cout, cin, 16, st);
     if (rc != 0) return rc;
     hipLaunchKernelGGL(winograd_out_kernel, gout, dim3(256), 0, st, Mw, h, w, cout / 4, TH, TW, t0, tc, bias, mask, relu,
                        out);
@@ -326,15 +358,14 @@ extern "C" {
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m) {
   if (tile_m == 4) {
     const size_t T4 = (size_t)((h + 3) / 4) * ((w + 3) / 4);
-    return ws_slice(36 * T4 * cin, sizeof(float)) + ws_slice(36 * T4 * cout, sizeof(float));
+    return ws_slice(36 * T4 * cin * 3 / 2, sizeof(float)) + ws_slice(36 * T4 * cout, sizeof(float));
   }
   const size_t T = (size_t)((h + 1) / 2) * ((w + 1) / 2);
-  return ws_slice(16 * T * cin * 3 / 2 + 64, sizeof(float)) + ws_slice(16 * T * cout, sizeof(float)) +
-         ws_slice((size_t)3 * 16 * cout * cin, sizeof(unsigned short));
+  return ws_slice(16 * T * cin, sizeof(float)) + ws_slice(16 * T * cout, sizeof(float));
 }
 
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok, const float* u_packed,
-                                 const float* bias, int cout, int tile_m, float* out, float* pool_out,
+                                 const void* u_x3, const float* bias, int cout, int tile_m, float* out, float* pool_out,
                                  unsigned char* pool_code, void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(in && u_pok && bias && out && workspace && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, STROTSS_EALIGN);
@@ -344,7 +375,7 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
   const bool fused = tile_m == 4 && u_packed && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout);
   int rc;
   if (tile_m == 4)
-    rc = winograd43_run(in, h, w, cin, u_pok, u_packed, bias, cout, nullptr, 1, out, pool_out, pool_code, workspace,
+    rc = winograd43_run(in, h, w, cin, u_pok, u_packed, u_x3, bias, cout, nullptr, 1, out, pool_out, pool_code, workspace,
                         workspace_bytes, (hipStream_t)stream);
   else
     rc = winograd_run(in, h, w, cin, u_pok, bias, cout, nullptr, 1, out, workspace, workspace_bytes,
@@ -354,16 +385,24 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
 }
 
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
-                                   const float* u_packed, int cin, int tile_m, const float* act_in, float* gin,
+                                   const float* u_packed, const void* u_x3, int cin, int tile_m, const float* act_in, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(gout && u_pik && gin && workspace && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   if (tile_m == 4)
-    return winograd43_run(gout, h, w, cout, u_pik, u_packed, nullptr, cin, act_in, 0, gin, nullptr, nullptr, workspace, workspace_bytes,
-                          (hipStream_t)stream);
+    return winograd43_run(gout, h, w, cout, u_pik, u_packed, u_x3, nullptr, cin, act_in, 0, gin, nullptr, nullptr, workspace,
+                          workspace_bytes, (hipStream_t)stream);
   return winograd_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
                       (hipStream_t)stream);
+}
+
+size_t strotss_conv3x3_winograd_x3_bytes(int rows, int k) { return (size_t)36 * 3 * rows * k * sizeof(unsigned short); }
+
+int strotss_conv3x3_winograd_x3pack(const float* u_prk, int rows, int k, void* u_x3, void* stream) {
+  ST_CHECK_ARG(u_prk && u_x3 && rows > 0 && k > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(k % 32 == 0, STROTSS_EALIGN);
+  return st_x3_split_rows(u_prk, rows, k, k, (long long)rows * k, u_x3, 36, (hipStream_t)stream);
 }
 
 int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_packed, void* stream) {

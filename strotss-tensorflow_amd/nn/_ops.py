@@ -127,6 +127,40 @@ def winograd_packed(u: torch.Tensor):
     return up
 
 
+_x3 = {}           # id(u) -> (weakref(u), panels): bf16x3 "x3 panels" of frozen F(4x4,3x3) weights
+
+
+def _x3_min_tiles() -> int:
+    import os
+    return int(os.environ.get("STROTSS_X3_MIN_TILES", "1024"))
+
+
+def winograd_x3(u: torch.Tensor, h: int, w: int):
+    """The x3 panels (three bf16 planes per f32 weight, K-blocked; csrc/mfma_x3.h) of a (36, rows, k) Winograd weight
+    tensor for the bf16x3 GEMM core (made once per tensor object; the weights are frozen), or None where the library
+    would not use them for an (h, w) layer: same policy as csrc/winograd.hip x3_enabled (at least
+    STROTSS_X3_MIN_TILES 128 x 128 GEMM tiles) on the layers the fused kernel does not take (rows > 256)."""
+    import os, weakref
+    rows = int(u.shape[1])
+    tiles = -(-(-(-h // 4) * -(-w // 4)) // 128) * -(-rows // 128) * 36
+    if int(u.shape[0]) != 36 or int(u.shape[2]) % 32 or os.environ.get("STROTSS_X3", "1") == "0":
+        return None
+    if tiles < _x3_min_tiles() or (rows <= 256 and os.environ.get("STROTSS_WINO_FUSED", "1") != "0"):
+        return None
+    hit = _x3.get(id(u))
+    if hit is not None and hit[0]() is u:
+        return hit[1]
+    require(u, "winograd weights")
+    rows, k = int(u.shape[1]), int(u.shape[2])
+    nb = _hip.lib().strotss_conv3x3_winograd_x3_bytes(rows, k)
+    up = torch.empty(nb // 2, dtype=torch.bfloat16, device=u.device)
+    check(_hip.lib().strotss_conv3x3_winograd_x3pack(ptr(u), rows, k, ptr(up), stream_ptr()), "conv3x3_winograd_x3pack")
+    for key in [key for key, v in _x3.items() if v[0]() is None]:
+        del _x3[key]
+    _x3[id(u)] = (weakref.ref(u), up)
+    return up
+
+
 def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None):
     """u_pok: (16, cout, cin) -> F(2x2,3x3), (36, cout, cin) -> F(4x4,3x3).  pool_out: (1, h//2, w//2, cout) buffer
     that also receives the 2x2/2 max-pool of the result."""
@@ -136,7 +170,8 @@ def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
     m = _tile_m(u_pok)
     ws, nb = _wino_ws(h, w, cin, cout, m, x.device)
-    check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(winograd_packed(u_pok)), ptr(bias),
+    check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(winograd_packed(u_pok)),
+                                                  ptr(winograd_x3(u_pok, h, w)), ptr(bias),
                                                   cout, m, ptr(out), ptr(pool_out), ptr(pool_code), ptr(ws), nb, stream_ptr()),
           "conv3x3_winograd_fwd")
     return out
@@ -148,7 +183,8 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
         out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
     m = _tile_m(u_pik)
     ws, nb = _wino_ws(h, w, cout, cin, m, gout.device)
-    check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), ptr(winograd_packed(u_pik)), cin,
+    check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), ptr(winograd_packed(u_pik)),
+                                                    ptr(winograd_x3(u_pik, h, w)), cin,
                                                     m, ptr(act_in), ptr(out), ptr(ws), nb, stream_ptr()),
           "conv3x3_winograd_dgrad")
     return out

@@ -131,26 +131,40 @@ def time_kernel_families(eng, idx, steps):
 
 
 def pairwise_roofline(dev, iters=50):
-    """The N x N x D cosine cost matrix (losses.py:12-15) on its own: algorithmic 2*N*N*D FLOP."""
+    """The N x N x D cosine cost matrix (losses.py:12-15) on its own, as the loss entry points run it: the bf16x3
+    GEMM core (csrc/mfma_x3.h: f32 operands split exactly into three bf16 planes, six exact partial products, f32
+    accumulation) with the fused cosine epilogue.  Algorithmic 2*N*N*D f32 FLOP / HIP-event time of one launch,
+    against the dense f32 MFMA peak (the arithmetic delivered is f32-class; the bf16 MFMA executes 6x that)."""
     from nn import _ops
     g = torch.Generator().manual_seed(3)
     x = torch.zeros(SAMPLES, _ops.pad32(D)); x[:, :D] = torch.relu(torch.randn(SAMPLES, D, generator=g))
-    x = x.to(dev)
-    r = _ops.row_inv_norm(x, SAMPLES)
+    y = torch.zeros(SAMPLES, _ops.pad32(D)); y[:, :D] = torch.relu(torch.randn(SAMPLES, D, generator=g))
+    x, y = x.to(dev), y.to(dev)
+    ld = int(x.shape[1])
+    x3 = os.environ.get("STROTSS_X3", "1") != "0"
+    if x3:
+        rx, px = _ops.row_inv_norm_x3(x, SAMPLES)
+        ry, py = _ops.row_inv_norm_x3(y, SAMPLES)
+        fn = lambda: _ops.cosine_distance_x3(px, rx, SAMPLES, py, ry, SAMPLES, ld)
+    else:
+        rx, ry = _ops.row_inv_norm(x, SAMPLES), _ops.row_inv_norm(y, SAMPLES)
+        fn = lambda: _ops.cosine_distance(x, rx, SAMPLES, y, ry, SAMPLES)
     for _ in range(5):
-        _ops.cosine_distance(x, r, SAMPLES, x, r, SAMPLES)
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        _ops.cosine_distance(x, r, SAMPLES, x, r, SAMPLES)
+        fn()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * SAMPLES * SAMPLES * D / (ms * 1e-3) / 1e12
-    return {"kernel": "gemm_kernel<64,64,KC,KC,EpiCosDist> (cosine cost matrix 1024x1024x2179)", "bound": "mfma",
-            "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
+    kern = ("gemm_x3_kernel<X3Cfg<64>, EpiCosDistX3> (cosine cost matrix 1024x1024x2179, style x prediction: full matrix; "
+            "bf16x3 core)" if x3 else "gemm_kc_pipe_kernel<64,64,EpiCosDist> (cosine cost matrix 1024x1024x2179, f32 MFMA)")
+    return {"kernel": kern, "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2), "traffic": None,
+            "executed_bf16_tflops": round(6 * tf, 1) if x3 else None, "bf16_mfma_peak_tflops": 2500.0 if x3 else None}
 
 
 def pmc_traffic(path=os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.csv")):

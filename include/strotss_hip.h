@@ -93,7 +93,8 @@ int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const fl
  * u_x3 (tile_m = 4 only, may be NULL): the same weights as "x3 panels" written by strotss_conv3x3_winograd_x3pack
  * (strotss_conv3x3_winograd_x3_bytes bytes).  With it, the 36 GEMMs of the three-kernel form run on the bf16 MFMA by
  * EXACT 3-way operand splitting (every f32 value = h + m + l in bf16, six exact partial products, f32 accumulation:
- * f32-class results at 6/16 of the f32-MFMA cost, csrc/mfma_x3.h); NULL or STROTSS_X3=0 keeps them on the f32 MFMA. */
+ * f32-class results at 6/16 of the f32-MFMA cost, csrc/mfma_x3.h).  OPT-IN: used only with STROTSS_X3_CONV=1 in the
+ * environment (the GEMMs run 1.55x faster, the power-limited step does not on every board: csrc/winograd.hip). */
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m);
 /* u_prk: (36, rows, k) -> x3 panels: per position p, element (r, c) split into bf16 planes h, m, l at
  * ((p * (k/32) + c/32) * 3 + plane) * rows * 32 + r * 32 + c % 32   (bf16 units).  k % 32 == 0. */
@@ -158,7 +159,15 @@ int strotss_row_inv_norm(const float* x, int n, int ld, float* r, void* stream);
 /* C[i,j] = 1 - <x_i,y_j> * rx[i]*ry[j], i < nx, j < ny   (losses.py:12-15) */
 int strotss_cosine_distance(const float* x, const float* rx, int nx, const float* y,
                             const float* ry, int ny, int ld, float* C, int ldc, void* stream);
-size_t strotss_selfsim_workspace_bytes(int n);
+/* The same two entry points on the bf16x3 GEMM core (csrc/mfma_x3.h): every f32 value is split EXACTLY into three
+ * bf16 values, six exact partial products, f32 accumulation -- f32-class results at 6/16 of the f32-MFMA cost.
+ * strotss_row_inv_norm_x3 also writes the rows as "x3 panels" (3 * n * ld bf16; element (i, k), plane p at
+ * ((k/32 * 3 + p) * n + i) * 32 + k%32); r may be NULL.  strotss_cosine_distance_x3 takes the panels of x and y;
+ * x == y gives an exactly symmetric matrix.  The loss entry points below use this core unless STROTSS_X3=0. */
+int strotss_row_inv_norm_x3(const float* x, int n, int ld, float* r, void* panels, void* stream);
+int strotss_cosine_distance_x3(const void* x_panels, const float* rx, int nx, const void* y_panels, const float* ry,
+                               int ny, int ld, float* C, int ldc, void* stream);
+size_t strotss_selfsim_workspace_bytes(int n, int ld);
 /* loss_out[0] = self_similarity(pred, content) (losses.py:55-66);
  * gpred += gscale * dloss/dpred.  pred/content: (rows >= n, ld). */
 int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int d, int ld,
@@ -175,7 +184,8 @@ size_t strotss_sinkhorn_workspace_bytes(int ns, int n, int n_iter);
 int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n, int d,
                                  int ld, float l, int n_iter, float gscale, float* gpred, float* loss_out,
                                  void* workspace, size_t workspace_bytes, void* stream);
-size_t strotss_remd_workspace_bytes(int ns, int n);
+/* ld = row stride of the feature matrices (strotss_remd_cos_fwd_bwd), 0 for strotss_palette_remd_fwd_bwd */
+size_t strotss_remd_workspace_bytes(int ns, int n, int ld);
 /* loss_out[0] = relaxed_emd(style, pred, 'cosine') (losses.py:69-80); gpred += gscale*dloss/dpred.
  * rs = row_inv_norm(style) (constant per scale). */
 int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n,
@@ -185,7 +195,7 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
  * gpred[:, :3] += gscale*dloss/dpred[:, :3].  style/pred are the full (rows, ld) matrices, of
  * which only the first three columns are read.  rgb_to_yuv != 0 applies convert_rgb_to_yuv
  * (strotss_utils.py:166-167) to them first; 0 takes them as they are (losses.relaxed_emd 'both').
- * Workspace: strotss_remd_workspace_bytes(ns, n). */
+ * Workspace: strotss_remd_workspace_bytes(ns, n, 0). */
 int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld,
                                  int rgb_to_yuv, float gscale, float* gpred, float* loss_out,
                                  void* workspace, size_t workspace_bytes, void* stream);

@@ -43,6 +43,16 @@ struct EpiCosDist {  // C = 1 - acc * (ra[i]*rb[j])      (losses.py:12-15)
   __device__ __forceinline__ void mirror(int r, int c, float val) const { C[(size_t)r * ldc + c] = val; }
   __device__ __forceinline__ void finish(float*, float) const {}
 };
+// The same on the bf16x3 core.  There the partial products of (i,j) and (j,i) are accumulated in different orders, so
+// symmetry is made exact by construction: only entries on or above the diagonal are stored by their owner, every
+// entry below is the mirrored copy of its transpose (diagonal tiles mirror their own strict upper triangle).
+struct EpiCosDistX3 : EpiCosDist {
+  static constexpr bool SYMM_DIAG = true;
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    if (r < M && c < N && !(symm && r > c)) C[(size_t)r * ldc + c] = value(r, c, v);
+    return 0.f;
+  }
+};
 struct EpiScaleStore {  // C = alpha * acc   (batched: C += z * strideC)
   static constexpr bool SYMM = false;
   float* C; int ldc; int M, N; float alpha; long long strideC;
@@ -106,14 +116,15 @@ struct EpiSelfsimBwd {
 
 // Writes the transpose of this workgroup's BM x BN tile (values val(r, c)) to (c, r) through LDS so that the mirrored
 // stores are row-contiguous.  `tile` holds >= BM * (BN + 1) floats.
-template <int BM, int BN, int NT, class Epi, class Val>
+// STRICT: only entries strictly above the diagonal are mirrored (a diagonal tile fills its own lower triangle).
+template <int BM, int BN, int NT, bool STRICT = false, class Epi, class Val>
 __device__ __forceinline__ void mirror_tile(const Epi& epi, float* tile, int m0, int n0, int M, int N, Val val) {
   __syncthreads();                                  // operands in LDS are dead
   val([&](int r, int c, float v) { tile[(r - m0) * (BN + 1) + (c - n0)] = v; });
   __syncthreads();
   for (int i = threadIdx.x; i < BM * BN; i += NT) {
     const int c = i / BM, r = i - c * BM;           // consecutive lanes: consecutive r = contiguous in the mirrored row
-    if (m0 + r < M && n0 + c < N) epi.mirror(n0 + c, m0 + r, tile[r * (BN + 1) + c]);
+    if (m0 + r < M && n0 + c < N && (!STRICT || n0 + c > m0 + r)) epi.mirror(n0 + c, m0 + r, tile[r * (BN + 1) + c]);
   }
 }
 
@@ -341,13 +352,47 @@ int st_x3_split_rows(const float* x, int rows, int ld, int K, long long stride_i
   ST_LAUNCH_RET();
 }
 
+struct X3NoMirror {
+  template <class Epi, class Acc, class Map>
+  __device__ __forceinline__ void operator()(const Epi&, float*, int, int, int, int, Acc&, const Map&) const {}
+};
+template <class Cfg>
+struct X3Mirror {       // writes the transpose of the workgroup's tile through LDS (mirror_tile above)
+  template <class Epi, class Acc, class Map>
+  __device__ __forceinline__ void operator()(const Epi& epi, float* tile, int m0, int n0, int M, int N, Acc& acc,
+                                             const Map& map) const {
+    mirror_tile<Cfg::BM, Cfg::BN, Cfg::NT, true>(epi, tile, m0, n0, M, N, [&](auto put) {
+#pragma unroll
+      for (int im = 0; im < Cfg::T; ++im)
+#pragma unroll
+        for (int in = 0; in < Cfg::T; ++in)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int r = m0 + map.row(im, reg), c = n0 + map.colof(in);
+            put(r, c, (r < M && c < N) ? epi.value(r, c, acc[im][in][reg]) : 0.f);
+          }
+    });
+  }
+};
+
 // C[z] (M x N, ldc) = A[z] B[z]^T, both operands as x3 panels of K columns (K % 32 == 0).
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
                        int batch, hipStream_t s) {
-  using Cfg = X3Cfg<128, 128>;
+  using Cfg = X3Cfg<128>;
   EpiScaleStore e{C, ldc, M, N, 1.0f, strideC};
   dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
-  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStore>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
-                     (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e);
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStore, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
+                     (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e, X3NoMirror{});
+  ST_LAUNCH_RET();
+}
+
+// st_cosine_distance on x3 panels of x and y (64 x 64 tiles: 256 workgroups at 1024 x 1024, two per CU).
+int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* yp, const float* ry, int ny, int K,
+                          int symm, float* C, int ldc, hipStream_t s) {
+  using Cfg = X3Cfg<64>;
+  EpiCosDistX3 e{{rx, ry, C, ldc, nx, ny, symm}};
+  dim3 grid((unsigned)cdiv(ny, 64) * cdiv(nx, 64));
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiCosDistX3, X3Mirror<Cfg>>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)xp, nx,
+                     0LL, (const __bf16*)yp, ny, 0LL, K, e, X3Mirror<Cfg>{});
   ST_LAUNCH_RET();
 }

@@ -26,6 +26,8 @@ int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned c
 // f32 GEMM cores on the bf16 MFMA (mfma_x3.h): operands as "x3 panels" (3 * rows * K bf16 per batch entry)
 int st_x3_split_rows(const float* x, int rows, int ld, int K, long long stride_in, void* panels, int batch,
                      hipStream_t s);
+int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* yp, const float* ry, int ny, int K,
+                          int symm, float* C, int ldc, hipStream_t s);
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
                        int batch, hipStream_t s);
 

@@ -1,7 +1,10 @@
 // Loss path of the STROTSS step (nn/losses.py:12-80, run_strotss.py:21-40): reductions and
 // sparse backward passes around the MFMA cost-matrix GEMMs of gemm.hip.  Every reduction
 // uses a fixed tree, so results are bitwise reproducible run to run.
+#include <stdlib.h>
+
 #include "internal.h"
+#include "mfma_x3.h"
 
 namespace {
 
@@ -19,6 +22,26 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restri
   }
   s = wave_sum(s);
   if (lane == 0) r[row] = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+}
+
+// The same pass also writing the row as x3 panels (mfma_x3.h: three bf16 planes per value, K-blocked) for the
+// bf16x3 cost-matrix GEMM.  r may be NULL (norms already known).  ld % 32 == 0.
+__global__ __launch_bounds__(256) void row_inv_norm_x3_kernel(const float* __restrict__ x, int n, int ld,
+                                                              float* __restrict__ r, __bf16* __restrict__ panels) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* p = x + (size_t)row * ld;
+  float s = 0.f;
+  for (int k = lane * 4; k < ld; k += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + k);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    x3_store4(panels, n, row, k, v);
+  }
+  if (r) {
+    s = wave_sum(s);
+    if (lane == 0) r[row] = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+  }
 }
 
 // s[i] = sum_{j<n} D[i,j]
@@ -502,11 +525,24 @@ __global__ __launch_bounds__(256) void sk_assemble_kernel(const float* __restric
 
 bool feat_ok(int n, int d, int ld) { return n > 0 && d > 0 && ld >= d; }
 
+// STROTSS_X3 = 0 or STROTSS_X3_COST = 0 keeps the cosine cost matrices on the f32 MFMA (default: bf16x3 core,
+// csrc/mfma_x3.h).
+bool cost_x3() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("STROTSS_X3"); on = e ? atoi(e) : 1;
+    const char* c = getenv("STROTSS_X3_COST"); if (c && atoi(c) == 0) on = 0;
+  }
+  return on != 0;
+}
+
 struct SelfsimWs {
   float *rp, *rc, *Dx, *Dy, *sx, *sy, *Q, *Mq, *qdot, *lossrow;
+  __bf16 *xp, *xc;               // x3 panels of pred / content (ld > 0)
   int ldc;
-  bool plan(Workspace& w, int n) {
+  bool plan(Workspace& w, int n, int ld) {
     ldc = round_up(n, 32);
+    xp = w.take<__bf16>((size_t)3 * n * ld); xc = w.take<__bf16>((size_t)3 * n * ld);
     rp = w.take<float>(ldc); rc = w.take<float>(ldc);
     Dx = w.take<float>((size_t)n * ldc); Dy = w.take<float>((size_t)n * ldc);
     sx = w.take<float>(ldc); sy = w.take<float>(ldc);
@@ -519,9 +555,11 @@ struct RemdWs {
   float *rp, *C, *rmin, *rcnt, *cmin, *ccnt, *pmin, *pcnt;
   f32x4 *ys, *yp;
   int* sel;
+  __bf16 *xp, *xs;     // x3 panels of pred / style (cosine REMD, ld > 0)
   int ldc, ldt;        // row stride of the style-major C[i][j] (palette) / of the pred-major Ct[j][i] (cosine REMD)
-  bool plan(Workspace& w, int ns, int n) {
+  bool plan(Workspace& w, int ns, int n, int ld) {
     ldc = round_up(n, 32);
+    xp = w.take<__bf16>((size_t)3 * n * ld); xs = w.take<__bf16>((size_t)3 * ns * ld);
     ldt = round_up(ns, 32);
     const int ldm = ldc > ldt ? ldc : ldt;
     rp = w.take<float>(ldc);
@@ -582,10 +620,26 @@ int strotss_cosine_distance(const float* x, const float* rx, int nx, const float
   return st_cosine_distance(x, rx, nx, y, ry, ny, ld, C, ldc, (hipStream_t)stream);
 }
 
-size_t strotss_selfsim_workspace_bytes(int n) {
+int strotss_row_inv_norm_x3(const float* x, int n, int ld, float* r, void* panels, void* stream) {
+  ST_CHECK_ARG(x && panels && n > 0 && ld > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, n, ld, r,
+                     (__bf16*)panels);
+  ST_LAUNCH_RET();
+}
+
+int strotss_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* yp, const float* ry, int ny,
+                               int ld, float* C, int ldc, void* stream) {
+  ST_CHECK_ARG(xp && rx && yp && ry && C && nx > 0 && ny > 0 && ldc >= ny, STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0 && ld > 0, STROTSS_EALIGN);
+  return st_cosine_distance_x3(xp, rx, nx, yp, ry, ny, ld, (xp == yp && rx == ry && nx == ny) ? 1 : 0, C, ldc,
+                               (hipStream_t)stream);
+}
+
+size_t strotss_selfsim_workspace_bytes(int n, int ld) {
   Workspace w = Workspace::planner();
   SelfsimWs s;
-  s.plan(w, n);
+  s.plan(w, n, ld);
   return w.off;
 }
 
@@ -596,14 +650,22 @@ int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int 
   ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
   Workspace w(workspace, workspace_bytes);
   SelfsimWs s;
-  ST_CHECK_ARG(s.plan(w, n), STROTSS_EINVAL);
+  ST_CHECK_ARG(s.plan(w, n, ld), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
   const int ldc = s.ldc;
-  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
-  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, content, n, ld, s.rc);
-  LAUNCH_OK();
-  CHK(st_cosine_distance(pred, s.rp, n, pred, s.rp, n, ld, s.Dx, ldc, st));
-  CHK(st_cosine_distance(content, s.rc, n, content, s.rc, n, ld, s.Dy, ldc, st));
+  if (cost_x3()) {      // cost matrices on the bf16x3 core: the norm pass also writes the rows' x3 panels
+    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp, s.xp);
+    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, content, n, ld, s.rc, s.xc);
+    LAUNCH_OK();
+    CHK(st_cosine_distance_x3(s.xp, s.rp, n, s.xp, s.rp, n, ld, 1, s.Dx, ldc, st));
+    CHK(st_cosine_distance_x3(s.xc, s.rc, n, s.xc, s.rc, n, ld, 1, s.Dy, ldc, st));
+  } else {
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, content, n, ld, s.rc);
+    LAUNCH_OK();
+    CHK(st_cosine_distance(pred, s.rp, n, pred, s.rp, n, ld, s.Dx, ldc, st));
+    CHK(st_cosine_distance(content, s.rc, n, content, s.rc, n, ld, s.Dy, ldc, st));
+  }
   hipLaunchKernelGGL(row_sum_kernel, dim3(n), dim3(256), 0, st, s.Dx, n, ldc, s.sx);
   hipLaunchKernelGGL(row_sum_kernel, dim3(n), dim3(256), 0, st, s.Dy, n, ldc, s.sy);
   // loss = mean(|A-B|) * n = (1/n) sum |A-B|  ->  dL/dA = sign/n
@@ -680,10 +742,10 @@ int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, co
   return st_selfsim_bwd_gemm(s.W, ldm, ldm, style, pred, s.rp, s.q, n, ld, gscale, gpred, st);
 }
 
-size_t strotss_remd_workspace_bytes(int ns, int n) {
+size_t strotss_remd_workspace_bytes(int ns, int n, int ld) {
   Workspace w = Workspace::planner();
   RemdWs s;
-  s.plan(w, ns, n);
+  s.plan(w, ns, n, ld);
   return w.off;
 }
 
@@ -696,16 +758,23 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   ST_CHECK_ARG(ns <= REMD_MAX_LIST, STROTSS_ERANGE);
   Workspace w(workspace, workspace_bytes);
   RemdWs s;
-  ST_CHECK_ARG(s.plan(w, ns, n), STROTSS_EINVAL);
+  ST_CHECK_ARG(s.plan(w, ns, n, ld), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
   const int ldc = s.ldc;
-  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+  const bool x3 = cost_x3();
+  if (x3) {
+    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp, s.xp);
+    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(ns, 4)), dim3(256), 0, st, style, ns, ld, (float*)nullptr, s.xs);
+  } else {
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+  }
   LAUNCH_OK();
   // pred-major cost matrix Ct[j][i] (bitwise the transpose of cosine_distance(style, pred): same products, same k
   // order), so that the backward kernel's scans of "column j" are contiguous: minima over i per prediction row j
   // are row minima (cmin), minima over j per style row i column minima (rmin)
   const int ldt = s.ldt;
-  CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.C, ldt, st));
+  if (x3) CHK(st_cosine_distance_x3(s.xp, s.rp, n, s.xs, rs, ns, ld, 0, s.C, ldt, st));
+  else CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.C, ldt, st));
   hipLaunchKernelGGL(row_min_kernel, dim3(n), dim3(256), 0, st, s.C, ns, ldt, s.cmin, s.ccnt);
   hipLaunchKernelGGL(col_min_partial_kernel, dim3(cdiv(ns, 64), COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.pmin,
                      s.pcnt);
@@ -723,7 +792,7 @@ int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, 
   ST_CHECK_ARG(style && pred && gpred && loss_out && workspace && ns > 0 && n > 0 && ld >= 3, STROTSS_EINVAL);
   Workspace w(workspace, workspace_bytes);
   RemdWs s;
-  ST_CHECK_ARG(s.plan(w, ns, n), STROTSS_EINVAL);
+  ST_CHECK_ARG(s.plan(w, ns, n, 0), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
   const int ldc = s.ldc;
   hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, st, style, ns, ld, s.ys, rgb_to_yuv);

@@ -19,8 +19,8 @@
 // arithmetic, no zero-select and no address arithmetic in the main loop (rows past the operand's end are
 // clamped at set-up; their products land in accumulator rows the epilogue masks).
 //
-// Block tile 128x128, 256 threads = 2x2 waves (64x64 per wave as 32x32 MFMA tiles), K-step 32 = 2 MFMA
-// k-chunks x 6 products x 4 tiles = 48 MFMAs per wave (see the main loop below).
+// Block tile 128x128 (or 64x64), 256 threads = 2x2 waves (64x64 | 32x32 per wave as 32x32 MFMA tiles), K-step 32
+// = 2 MFMA k-chunks x 6 products x 4 | 1 tiles = 48 | 12 MFMAs per wave (see the main loop below).
 #pragma once
 #include <type_traits>
 
@@ -64,20 +64,25 @@ __device__ __forceinline__ void x3_store4(__bf16* base, size_t rows, size_t row,
 // stage (s+2) % 3 (free since the barrier of step s-1), one `s_waitcnt vmcnt(12)` (tile s+1 landed, tile
 // s+2 stays in flight ACROSS the barrier) + lgkmcnt(0) + raw s_barrier in the second k-chunk, then the first
 // fragments of tile s+1.  No staging registers, no ds_write, no VALU in the loop besides 4 address adds.
-template <int BM_, int BN_>
-struct X3Cfg {
-  static_assert(BM_ == 128 && BN_ == 128, "x3 main loop is written for 128 x 128 tiles");
-  static constexpr int BM = BM_, BN = BN_, WM = 2, WN = 2, NT = 256, TM = 2, TN = 2;
-  static constexpr int PL = 128 * 64;                    // bytes of one plane image
-  static constexpr int STAGE = 6 * PL;                   // 48 KiB
-  static constexpr int LDS_BYTES = 3 * STAGE;            // 144 KiB
+template <int B_>
+struct X3Cfg {               // square block tile B x B, B = 128 (64 x 64 per wave) or 64 (32 x 32 per wave)
+  static_assert(B_ == 128 || B_ == 64, "x3 main loop: 128 x 128 or 64 x 64 tiles");
+  static constexpr int BM = B_, BN = B_, WM = 2, WN = 2, NT = 256;
+  static constexpr int T = B_ / 64;                      // 32x32 MFMA tiles per wave and dimension
+  static constexpr int TM = T, TN = T;
+  static constexpr int PL = B_ * 64;                     // bytes of one plane image ([B rows][64 B])
+  static constexpr int STAGE = 6 * PL;                   // 48 KiB | 24 KiB
+  static constexpr int LDS_BYTES = 3 * STAGE;            // 144 KiB (one workgroup per CU) | 72 KiB (two)
+  static constexpr int G = B_ / 64;                      // 16-row DMA groups per wave, operand and plane
+  static constexpr int NP = 6 * G;                       // DMA pieces (1 KiB wave instructions) per wave and K-step
 };
 
 #define X3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+template <int G>
 struct X3Operand {          // one x3 panel operand as seen by one wave's DMA lanes
   const char* base;          // batch base, bytes
-  unsigned off[2];           // byte offset of this lane's 16-byte source chunk within a plane panel, 2 row groups
+  unsigned off[G];           // byte offset of this lane's 16-byte source chunk within a plane panel, per row group
   unsigned plane;            // bytes per plane panel (rows * 64)
   unsigned cur;              // byte offset of the current K-block (3 planes per K-block)
   __device__ __forceinline__ X3Operand(const __bf16* p, int rows, int row0) {
@@ -87,8 +92,8 @@ struct X3Operand {          // one x3 panel operand as seen by one wave's DMA la
     cur = 0;
     const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // source-side swizzle: (row >> 2) & 3 == (lane >> 4) & 3
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int row = min(row0 + (2 * wave + g) * 16 + (lane >> 2), rows - 1);
+    for (int g = 0; g < G; ++g) {
+      const int row = min(row0 + (G * wave + g) * 16 + (lane >> 2), rows - 1);
       off[g] = (unsigned)row * 64u + (unsigned)chunk * 16u;
     }
   }
@@ -101,34 +106,35 @@ struct X3Operand {          // one x3 panel operand as seen by one wave's DMA la
 };
 
 template <class Cfg>
-__device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Operand& oa, X3Operand& ob,
-                                             f32x16 (&acc)[2][2]) {
-  constexpr int PL = Cfg::PL, STAGE = Cfg::STAGE;
+__device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Operand<Cfg::G>& oa, X3Operand<Cfg::G>& ob,
+                                            f32x16 (&acc)[Cfg::T][Cfg::T]) {
+  constexpr int PL = Cfg::PL, STAGE = Cfg::STAGE, T = Cfg::T, G = Cfg::G, NP = Cfg::NP, HALF = Cfg::BM / 2;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
-  // DMA piece j of a K-step (12 per wave): operand j / 6, plane (j % 6) / 2, row group j % 2
+  // DMA piece j of a K-step (NP per wave): operand j / (3 G), plane (j % (3 G)) / G, row group j % G
   auto dma_piece = [&](int j, unsigned char* stage) {
-    const int op = j / 6, pl = (j % 6) / 2, g = j % 2;
-    unsigned char* dst = stage + (op * 3 + pl) * PL + (2 * wave + g) * 1024;
+    const int op = j / (3 * G), pl = (j % (3 * G)) / G, g = j % G;
+    unsigned char* dst = stage + (op * 3 + pl) * PL + (G * wave + g) * 1024;
     if (op == 0) oa.dma(pl, g, dst); else ob.dma(pl, g, dst);
   };
   auto dma_tile = [&](unsigned char* stage) {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) dma_piece(j, stage);
+    for (int j = 0; j < NP; ++j) dma_piece(j, stage);
     oa.advance(); ob.advance();
   };
+  auto wait_one_tile_in_flight = [&]() { if constexpr (NP == 12) X3_WAIT_VM(12); else X3_WAIT_VM(6); };
   // fragment read offsets within a stage: row-major 64-byte rows, slot = (2 kc + hh) ^ ((row >> 2) & 3)
   const int f = (l31 >> 2) & 3;
-  const int a_rd = (wm * 64 + l31) * 64 + ((hh ^ f) << 4);              // kc = 0; kc = 1 is this ^ 32
-  const int b_rd = 3 * PL + (wn * 64 + l31) * 64 + ((hh ^ f) << 4);
-  bf16x8 fa[2][3][2], fb[2][3][2];
+  const int a_rd = (wm * HALF + l31) * 64 + ((hh ^ f) << 4);              // kc = 0; kc = 1 is this ^ 32
+  const int b_rd = 3 * PL + (wn * HALF + l31) * 64 + ((hh ^ f) << 4);
+  bf16x8 fa[2][3][T], fb[2][3][T];
   auto read_frags = [&](const unsigned char* stage, int kc, int slot) {
     const unsigned char* pa = stage + (a_rd ^ (kc << 5));
     const unsigned char* pb = stage + (b_rd ^ (kc << 5));
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < T; ++i) {
         fa[slot][p][i] = *reinterpret_cast<const bf16x8*>(pa + p * PL + i * 2048);
         fb[slot][p][i] = *reinterpret_cast<const bf16x8*>(pb + p * PL + i * 2048);
       }
@@ -141,7 +147,7 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
   unsigned char* s_nxt = lds + STAGE;
   unsigned char* s_nn = lds + 2 * STAGE;
   dma_tile(s_cur);
-  if (steps > 1) { dma_tile(s_nxt); X3_WAIT_VM(12); } else { X3_WAIT_VM(0); }
+  if (steps > 1) { dma_tile(s_nxt); wait_one_tile_in_flight(); } else { X3_WAIT_VM(0); }
   __builtin_amdgcn_s_barrier();
   read_frags(s_cur, 0, 0);
 
@@ -158,19 +164,19 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
+        for (int im = 0; im < T; ++im) {
 #pragma unroll
-          for (int in_ = 0; in_ < 2; ++in_)
+          for (int in_ = 0; in_ < T; ++in_)
             acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][PA[q]][im], fb[c][PB[q]][in_], acc[im][in_], 0, 0, 0);
-          if (MODE == 2 && c == 0) {
+          if (MODE == 2 && c == 0) {     // one DMA piece behind every T MFMAs: NP = 6 T pieces over the 6 T groups
             __builtin_amdgcn_sched_barrier(0);
-            dma_piece(2 * q + im, s_nn);
+            dma_piece(T * q + im, s_nn);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
         if (c == 1 && q == 0 && MODE != 0) {
           __builtin_amdgcn_sched_barrier(0);
-          if (MODE == 2) X3_WAIT_VM(12); else X3_WAIT_VM(0);
+          if (MODE == 2) wait_one_tile_in_flight(); else X3_WAIT_VM(0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
@@ -188,35 +194,47 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
   kstep(std::integral_constant<int, 0>{});
 }
 
-template <class Cfg, class Epi>
+// C[z] (M x N) = A[z] B[z]^T on x3 panels; 1-D launch of cdiv(M,B) * cdiv(N,B) * batch workgroups in XCD-aware
+// order (N-tile fastest, then M-tile, then batch: an XCD's 32 CUs share one batch's panels in their L2).
+// Epilogues as in gemm.hip (apply / finish; SYMM epilogues also value / mirror and a run-time `symm` switch:
+// tiles below the diagonal are skipped and written as the transpose of the tile above, bitwise symmetric).
+template <class Cfg, class Epi, class Mirror>
 __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restrict__ A, int M, long long strideA,
-                                                           const __bf16* __restrict__ B, int N, long long strideB,
-                                                           int K, Epi epi) {
+                                                          const __bf16* __restrict__ B, int N, long long strideB,
+                                                          int K, Epi epi, Mirror mirror) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDS_BYTES];
   const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
   const unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
   const unsigned bz = tile / (gx * gy), rem = tile - bz * (gx * gy);
   epi.set_batch(bz);
   const int m0 = (rem / gx) * Cfg::BM, n0 = (rem % gx) * Cfg::BN;
-  X3Operand oa(A + (long long)bz * strideA, M, m0);
-  X3Operand ob(B + (long long)bz * strideB, N, n0);
-  f32x16 acc[2][2];
+  if constexpr (Epi::SYMM) {
+    if (epi.symm && n0 < m0) return;                // mirrored by the tile above the diagonal
+  }
+  X3Operand<Cfg::G> oa(A + (long long)bz * strideA, M, m0);
+  X3Operand<Cfg::G> ob(B + (long long)bz * strideB, N, n0);
+  f32x16 acc[Cfg::T][Cfg::T];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < Cfg::T; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < Cfg::T; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   x3_mainloop<Cfg>(lds, K >> 5, oa, ob, acc);
   PipeAccMap<Cfg> map;
   float local = 0.f;
 #pragma unroll
-  for (int im = 0; im < 2; ++im)
+  for (int im = 0; im < Cfg::T; ++im)
 #pragma unroll
-    for (int in = 0; in < 2; ++in)
+    for (int in = 0; in < Cfg::T; ++in)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
         local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
+  if constexpr (Epi::SYMM) {
+    static_assert(!Epi::SYMM || Cfg::LDS_BYTES >= Cfg::BM * (Cfg::BN + 1) * 4, "mirror tile");
+    // SYMM epilogues on this core store only the upper triangle themselves: diagonal tiles mirror too
+    if (epi.symm && n0 >= m0) mirror(epi, reinterpret_cast<float*>(lds), m0, n0, M, N, acc, map);
+  }
   __syncthreads();
   epi.finish(reinterpret_cast<float*>(lds), local);
 }

@@ -143,7 +143,8 @@ def winograd_x3(u: torch.Tensor, h: int, w: int):
     import os, weakref
     rows = int(u.shape[1])
     tiles = -(-(-(-h // 4) * -(-w // 4)) // 128) * -(-rows // 128) * 36
-    if int(u.shape[0]) != 36 or int(u.shape[2]) % 32 or os.environ.get("STROTSS_X3", "1") == "0":
+    if int(u.shape[0]) != 36 or int(u.shape[2]) % 32 or os.environ.get("STROTSS_X3", "1") == "0" \
+            or os.environ.get("STROTSS_X3_CONV", "0") == "0":           # opt-in, see csrc/winograd.hip x3_enabled
         return None
     if tiles < _x3_min_tiles() or (rows <= 256 and os.environ.get("STROTSS_WINO_FUSED", "1") != "0"):
         return None
@@ -300,9 +301,28 @@ def cosine_distance(x, rx, nx, y, ry, ny) -> torch.Tensor:
     return Cm
 
 
+def row_inv_norm_x3(x, n):
+    """(r, panels): the row norms' reciprocals and the rows as x3 panels (three bf16 planes per value) for
+    cosine_distance_x3."""
+    require(x, "feature matrix")
+    r = torch.empty(pad32(n), dtype=torch.float32, device=x.device)
+    panels = torch.empty(3 * n * x.shape[1], dtype=torch.bfloat16, device=x.device)
+    check(_hip.lib().strotss_row_inv_norm_x3(ptr(x), n, x.shape[1], ptr(r), ptr(panels), stream_ptr()), "row_inv_norm_x3")
+    return r, panels
+
+
+def cosine_distance_x3(xp, rx, nx, yp, ry, ny, ld) -> torch.Tensor:
+    """cosine_distance on the bf16x3 GEMM core from the x3 panels of x and y (row_inv_norm_x3)."""
+    ldc = pad32(ny)
+    Cm = torch.empty((nx, ldc), dtype=torch.float32, device=rx.device)
+    check(_hip.lib().strotss_cosine_distance_x3(ptr(xp), ptr(rx), nx, ptr(yp), ptr(ry), ny, ld, ptr(Cm), ldc,
+                                                stream_ptr()), "cosine_distance_x3")
+    return Cm
+
+
 def selfsim_fwd_bwd(pred, content, n, d, gscale, gpred, loss_out):
     l = _hip.lib()
-    nb = l.strotss_selfsim_workspace_bytes(n)
+    nb = l.strotss_selfsim_workspace_bytes(n, pred.shape[1])
     ws = workspaces.get("selfsim", nb, pred.device)
     check(l.strotss_selfsim_fwd_bwd(ptr(pred), ptr(content), n, d, pred.shape[1], gscale, ptr(gpred),
                                     ptr(loss_out), ptr(ws), nb, stream_ptr()), "selfsim_fwd_bwd")
@@ -310,7 +330,7 @@ def selfsim_fwd_bwd(pred, content, n, d, gscale, gpred, loss_out):
 
 def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out):
     l = _hip.lib()
-    nb = l.strotss_remd_workspace_bytes(ns, n)
+    nb = l.strotss_remd_workspace_bytes(ns, n, pred.shape[1])
     ws = workspaces.get("remd", nb, pred.device)
     check(l.strotss_remd_cos_fwd_bwd(ptr(style), ptr(rs), ns, ptr(pred), n, d, pred.shape[1], gscale,
                                      ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "remd_cos_fwd_bwd")
@@ -327,7 +347,7 @@ def sinkhorn_cos_fwd_bwd(style, rs, ns, pred, n, d, l, n_iter, gscale, gpred, lo
 
 def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out, rgb_to_yuv=True):
     l = _hip.lib()
-    nb = l.strotss_remd_workspace_bytes(ns, n)
+    nb = l.strotss_remd_workspace_bytes(ns, n, 0)
     ws = workspaces.get("remd", nb, pred.device)
     assert style.shape[1] == pred.shape[1]
     check(l.strotss_palette_remd_fwd_bwd(ptr(style), ns, ptr(pred), n, pred.shape[1], int(rgb_to_yuv), gscale,

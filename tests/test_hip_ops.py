@@ -161,7 +161,7 @@ def test_conv_winograd_fwd_and_dgrad(ops, cfg, tile_m):
 
 
 def test_x3_gemm_accuracy():
-    """bf16x3 GEMM core of the Winograd form (csrc/mfma_x3.h, default on; STROTSS_X3=0 = f32 MFMA): f32 operands
+    """bf16x3 GEMM core of the Winograd form (csrc/mfma_x3.h, STROTSS_X3_CONV=1; default = f32 MFMA): f32 operands
     are split EXACTLY into three bf16 planes, six exact partial products, f32 accumulation.  The error against
     fp64 must stay at the native f32-MFMA path's level, on a shape with ragged tiles (T = 60 rows, not a
     multiple of the 128-row block, of 8 or of 16).  One subprocess per mode (the switch is read once per process)."""
@@ -186,7 +186,7 @@ print(json.dumps(res))
        os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = {}
     for mode in ("0", "1"):
-        env = dict(os.environ, STROTSS_X3=mode, STROTSS_X3_MIN_TILES="0", STROTSS_WINO_FUSED="0")     # three-kernel form, x3 on every shape
+        env = dict(os.environ, STROTSS_X3_CONV=mode, STROTSS_X3_MIN_TILES="0", STROTSS_WINO_FUSED="0")     # three-kernel form, x3 on every shape
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         res[mode] = json.loads(out.stdout.strip().splitlines()[-1])
@@ -271,6 +271,15 @@ def test_cosine_distance_and_norms(ops, n, d):
     # bitwise symmetry of the self-distance matrix (the row-sum == column-sum argument rests on it)
     D = ops.cosine_distance(bx, rx, n, bx, rx, n)[:, :n]
     assert torch.equal(D, D.T)
+    # the same on the bf16x3 core (what the loss entry points run): f32-class accuracy, exact symmetry, identical norms
+    rx3, px = ops.row_inv_norm_x3(bx, n)
+    ry3, py = ops.row_inv_norm_x3(by, n - 5)
+    assert torch.equal(rx3[:n], rx[:n]) and torch.equal(ry3[:n - 5], ry[:n - 5])
+    C3 = ops.cosine_distance_x3(px, rx3, n, py, ry3, n - 5, bx.shape[1])[:, :n - 5].cpu().numpy()
+    assert np.abs(C3 - R.cosine_distance(x, y)).max() < 2e-6
+    D3 = ops.cosine_distance_x3(px, rx3, n, px, rx3, n, bx.shape[1])[:, :n]
+    assert torch.equal(D3, D3.T)
+    assert (D3 - D).abs().max() < 2e-6
 
 
 @pytest.mark.parametrize("n,ns,d", [(48, 48, 35), (100, 70, 131), (256, 300, 259)])

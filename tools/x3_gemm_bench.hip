@@ -10,6 +10,7 @@
 #include "../strotss-tensorflow_amd/csrc/mfma_x3.h"
 
 struct EpiStore {
+  static constexpr bool SYMM = false;
   float* C; int ldc; int M, N; long long strideC;
   __device__ __forceinline__ void set_batch(int z) { C += (long long)z * strideC; }
   __device__ __forceinline__ float apply(int r, int c, float v) const {
@@ -42,13 +43,18 @@ int main(int argc, char** argv) {
                        (long long)3 * rows * K);
   };
   split(dA, M, pA); split(dB, N, pB);
-  using Cfg = X3Cfg<128, 128>;
-#define KERNEL gemm_x3_kernel
+#ifndef TILE
+#define TILE 128
+#endif
+  using Cfg = X3Cfg<TILE>;
+  struct NoMirror {
+    __device__ void operator()(const EpiStore&, float*, int, int, int, int, f32x16 (&)[Cfg::T][Cfg::T], const PipeAccMap<Cfg>&) const {}
+  };
   EpiStore e{dC, N, M, N, (long long)M * N};
-  dim3 grid((unsigned)(((M + 127) / 128) * ((N + 127) / 128) * batch));
+  dim3 grid((unsigned)(((M + TILE - 1) / TILE) * ((N + TILE - 1) / TILE) * batch));
   auto run = [&]() {
-    hipLaunchKernelGGL((KERNEL<Cfg, EpiStore>), grid, dim3(256), 0, st, pA, M, (long long)3 * M * K, pB, N,
-                       (long long)3 * N * K, K, e);
+    hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiStore, NoMirror>), grid, dim3(256), 0, st, pA, M, (long long)3 * M * K, pB, N,
+                       (long long)3 * N * K, K, e, NoMirror{});
   };
   run(); CK(hipStreamSynchronize(st)); CK(hipGetLastError());
   std::vector<float> hC((size_t)batch * M * N);

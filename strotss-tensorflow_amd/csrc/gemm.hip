@@ -47,9 +47,12 @@ struct EpiCosDist {  // C = 1 - acc * (ra[i]*rb[j])      (losses.py:12-15)
 // symmetry is made exact by construction: only entries on or above the diagonal are stored by their owner, every
 // entry below is the mirrored copy of its transpose (diagonal tiles mirror their own strict upper triangle).
 struct EpiCosDistX3 : EpiCosDist {
-  static constexpr bool SYMM_DIAG = true;
+  __device__ __forceinline__ float value(int r, int c, float v) const {     // unconditional loads (clamped addresses)
+    return 1.0f - v * (ra[min(r, M - 1)] * rb[min(c, N - 1)]);
+  }
   __device__ __forceinline__ float apply(int r, int c, float v) const {
-    if (r < M && c < N && !(symm && r > c)) C[(size_t)r * ldc + c] = value(r, c, v);
+    const float d = value(r, c, v);
+    if (r < M && c < N && !(symm && r > c)) C[(size_t)r * ldc + c] = d;
     return 0.f;
   }
 };
@@ -383,6 +386,116 @@ int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long lon
   dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
   hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStore, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
                      (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e, X3NoMirror{});
+  ST_LAUNCH_RET();
+}
+
+struct EpiAxpbyBiasX3 : EpiAxpbyBias {   // as EpiAxpbyBias with independent, unconditional loads (see EpiMomentFwdX3)
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    float* p = &C[(size_t)min(r, M - 1) * ldc + min(c, N - 1)];
+    const float out = *p + alpha * v + bias_scale * bias[min(c, N - 1)];
+    if (r < M && c < N) *p = out;
+    return 0.f;
+  }
+};
+// moment_matching on the x3 core.  Forward: Pt = x3 panels of the centred prediction rows TRANSPOSED (rows = feature,
+// K = sample index, zero-padded to a multiple of 32); the covariance difference's sign matrix T goes out as a
+// single-plane bf16 panel (values -1, 0, 1 are exact), which is the B operand of the backward product.
+struct EpiMomentFwdX3 {
+  static constexpr bool SYMM = true;
+  static constexpr int symm = 1;
+  const float* Sx; __bf16* Tp; int ld; int M, N; float inv_n; float* partial;
+  __device__ __forceinline__ void set_batch(int) {}
+  // Branch-free with clamped addresses: one workgroup per CU has nothing to hide a load behind, so the 64 loads of a
+  // lane must be independent and unconditional for the compiler to issue them back to back (inside `if`s they were
+  // waited for one by one: 45 us of epilogue per tile).
+  __device__ __forceinline__ float sx(int r, int c) const { return Sx[(size_t)min(r, M - 1) * ld + min(c, N - 1)]; }
+  __device__ __forceinline__ float value(int r, int c, float v) const { return signf(v * inv_n - sx(r, c)); }
+  // the owner of the upper triangle counts |diff| (twice off the diagonal); T is written by X3MomentStore below
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    const float a = fabsf(v * inv_n - sx(r, c));
+    const float w = (r < M && c < N && r <= c) ? (r == c ? 1.f : 2.f) : 0.f;
+    return w * a;
+  }
+  __device__ __forceinline__ void finish(float* red, float local) const {
+    const float s = block_sum_256(local, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  }
+};
+// Writes the tile's sign values into the single-plane panel Tp -- as they stand AND transposed (tiles below the
+// diagonal are never computed) -- from an LDS copy, 8 bf16 = 16 bytes per store (2-byte global stores straight from
+// the accumulators made this kernel 2.4x slower).  Diagonal tiles are symmetrised in LDS first (upper triangle wins).
+template <class Cfg>
+struct X3MomentStore {
+  template <class Acc, class Map>
+  __device__ __forceinline__ void operator()(const EpiMomentFwdX3& epi, float* tile, int m0, int n0, int M, int N,
+                                             Acc& acc, const Map& map) const {
+    constexpr int B = Cfg::BM, LD = B + 1;
+    __syncthreads();                                  // operands in LDS are dead
+#pragma unroll
+    for (int im = 0; im < Cfg::T; ++im)
+#pragma unroll
+      for (int in = 0; in < Cfg::T; ++in)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = map.row(im, reg), c = map.colof(in);
+          tile[r * LD + c] = epi.value(m0 + r, n0 + c, acc[im][in][reg]);      // out-of-range entries are never stored
+        }
+    __syncthreads();
+    const bool diag = n0 == m0;
+    if (diag) {
+      for (int i = threadIdx.x; i < B * B; i += Cfg::NT) {
+        const int r = i / B, c = i - r * B;
+        if (r > c) tile[r * LD + c] = tile[c * LD + r];
+      }
+      __syncthreads();
+    }
+    auto put8 = [&](int row, int k0, const float (&v)[8]) {       // 8 consecutive k of one panel row
+      bf16x8 o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q];
+      *reinterpret_cast<bf16x8*>(epi.Tp + ((size_t)(k0 >> 5) * epi.ld + row) * 32 + (k0 & 31)) = o;
+    };
+    for (int i = threadIdx.x; i < B * (B / 8); i += Cfg::NT) {   // as it stands: row m0 + r, k = n0 + c8 ..
+      const int r = i / (B / 8), c8 = (i - r * (B / 8)) * 8;
+      if (m0 + r >= M || n0 + c8 >= N) continue;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = tile[r * LD + c8 + q];
+      put8(m0 + r, n0 + c8, v);
+    }
+    if (!diag) {
+      for (int i = threadIdx.x; i < B * (B / 8); i += Cfg::NT) { // transposed: row n0 + c, k = m0 + r8 ..
+        const int c = i % B, r8 = (i / B) * 8;
+        if (n0 + c >= N || m0 + r8 >= M) continue;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = tile[(r8 + q) * LD + c];
+        put8(n0 + c, m0 + r8, v);
+      }
+    }
+  }
+};
+
+int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
+                     int* n_partial, hipStream_t s) {
+  using Cfg = X3Cfg<128>;
+  EpiMomentFwdX3 e{Sx, (__bf16*)Tp, ld, ld, ld, inv_n, partial};
+  const int g = cdiv(ld, 128);
+  *n_partial = g * g;
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiMomentFwdX3, X3MomentStore<Cfg>>), dim3(g * g), dim3(Cfg::NT), 0, s,
+                     (const __bf16*)Pt, ld, 0LL, (const __bf16*)Pt, ld, 0LL, npad, e, X3MomentStore<Cfg>{});
+  ST_LAUNCH_RET();
+}
+
+// dY(n x ld) += alpha * c(n x ld) @ T(ld x ld, symmetric) + bias_scale * bias[c]: c as x3 panels, T as the
+// single-plane panel written by st_moment_fwd_x3 (three partial products instead of six).
+int st_moment_bwd_x3(const void* Pc, int n, int ld, const void* Tp, float alpha, const float* bias, float bias_scale,
+                     float* dY, hipStream_t s) {
+  using Cfg = X3Cfg<128, 1>;
+  EpiAxpbyBiasX3 e{{dY, ld, n, ld, alpha, bias, bias_scale}};
+  dim3 grid((unsigned)cdiv(ld, 128) * cdiv(n, 128));
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiAxpbyBiasX3, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)Pc, n, 0LL,
+                     (const __bf16*)Tp, ld, 0LL, ld, e, X3NoMirror{});
   ST_LAUNCH_RET();
 }
 

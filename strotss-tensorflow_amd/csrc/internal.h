@@ -28,6 +28,10 @@ int st_x3_split_rows(const float* x, int rows, int ld, int K, long long stride_i
                      hipStream_t s);
 int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* yp, const float* ry, int ny, int K,
                           int symm, float* C, int ldc, hipStream_t s);
+int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
+                     int* n_partial, hipStream_t s);
+int st_moment_bwd_x3(const void* Pc, int n, int ld, const void* Tp, float alpha, const float* bias, float bias_scale,
+                     float* dY, hipStream_t s);
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
                        int batch, hipStream_t s);
 

@@ -387,6 +387,31 @@ __global__ __launch_bounds__(256) void center_kernel(const float* __restrict__ y
     reinterpret_cast<f32x4*>(cy)[e] = v;
   }
 }
+// The centred rows as x3 panels (mfma_x3.h) for the bf16x3 moment GEMMs, both ways round: Pc (rows = samples i < n,
+// K = ld features: the backward product's A) and Pt (rows = ld features, K = npad samples, zeros for i >= n: both
+// operands of the covariance).  One 32 x 32 tile per workgroup, transposed through LDS; grid (ld/32, npad/32).
+__global__ __launch_bounds__(256) void center_x3_kernel(const float* __restrict__ y, int n, int npad, int ld,
+                                                        const float* __restrict__ mean, __bf16* __restrict__ Pc,
+                                                        __bf16* __restrict__ Pt) {
+  __shared__ float tile[32][33];
+  const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  {
+    const int il = threadIdx.x >> 3, j4 = threadIdx.x & 7;
+    const int i = i0 + il, j = j0 + 4 * j4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+      v = *reinterpret_cast<const f32x4*>(y + (size_t)i * ld + j) - *reinterpret_cast<const f32x4*>(mean + j);
+      x3_store4(Pc, n, i, j, v);
+    }
+    tile[il][4 * j4 + 0] = v[0]; tile[il][4 * j4 + 1] = v[1]; tile[il][4 * j4 + 2] = v[2]; tile[il][4 * j4 + 3] = v[3];
+  }
+  __syncthreads();
+  {
+    const int ic = threadIdx.x & 7, jl = threadIdx.x >> 3;
+    const f32x4 v = {tile[4 * ic][jl], tile[4 * ic + 1][jl], tile[4 * ic + 2][jl], tile[4 * ic + 3][jl]};
+    x3_store4(Pt, ld, j0 + jl, i0 + 4 * ic, v);
+  }
+}
 // loss = sum(partial)/d^2 + sum_c |mx-my|/d ;  sgn[c] = sign(my - mx)
 __global__ __launch_bounds__(256) void moment_finalize_kernel(const float* __restrict__ partial, int count,
                                                               const float* __restrict__ mx,
@@ -525,6 +550,16 @@ __global__ __launch_bounds__(256) void sk_assemble_kernel(const float* __restric
 
 bool feat_ok(int n, int d, int ld) { return n > 0 && d > 0 && ld >= d; }
 
+// STROTSS_X3 = 0 or STROTSS_X3_MOMENT = 0 keeps the covariance GEMMs of moment_matching on the f32 MFMA.
+bool moment_x3() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("STROTSS_X3"); on = e ? atoi(e) : 1;
+    const char* c = getenv("STROTSS_X3_MOMENT"); if (c && atoi(c) == 0) on = 0;
+  }
+  return on != 0;
+}
+
 // STROTSS_X3 = 0 or STROTSS_X3_COST = 0 keeps the cosine cost matrices on the f32 MFMA (default: bf16x3 core,
 // csrc/mfma_x3.h).
 bool cost_x3() {
@@ -589,9 +624,11 @@ struct SinkhornWs {
 };
 struct MomentWs {
   float *mean, *cy, *T, *partial, *sgn, *psum;
+  __bf16 *Pc, *Pt, *Tp;          // x3 panels: centred rows, their transpose, the sign matrix (one plane)
   int rows;
   bool plan(Workspace& w, int n, int ld) {
     rows = round_up(n, 32);
+    Pc = w.take<__bf16>((size_t)3 * n * ld); Pt = w.take<__bf16>((size_t)3 * ld * rows); Tp = w.take<__bf16>((size_t)ld * ld);
     mean = w.take<float>(ld);
     cy = w.take<float>((size_t)rows * ld);
     T = w.take<float>((size_t)ld * ld);
@@ -845,11 +882,19 @@ int strotss_moment_fwd_bwd(const float* style_mean, const float* style_cov, cons
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(ld, 64), COL_CHUNKS), dim3(256), 0, st, pred, n, ld, s.psum);
   hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, st, s.psum, n, ld, s.mean);
-  hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st,
-                     pred, n, s.rows, ld, s.mean, s.cy);
-  LAUNCH_OK();
+  const bool x3 = moment_x3();
   int n_partial = 0;
-  CHK(st_moment_fwd_gemm(s.cy, s.rows, ld, style_cov, s.T, 1.0f / (float)n, s.partial, &n_partial, st));
+  if (x3) {           // both GEMMs on the bf16x3 core (csrc/mfma_x3.h)
+    hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, s.rows / 32), dim3(256), 0, st, pred, n, s.rows, ld, s.mean, s.Pc,
+                       s.Pt);
+    LAUNCH_OK();
+    CHK(st_moment_fwd_x3(s.Pt, s.rows, ld, style_cov, s.Tp, 1.0f / (float)n, s.partial, &n_partial, st));
+  } else {
+    hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st,
+                       pred, n, s.rows, ld, s.mean, s.cy);
+    LAUNCH_OK();
+    CHK(st_moment_fwd_gemm(s.cy, s.rows, ld, style_cov, s.T, 1.0f / (float)n, s.partial, &n_partial, st));
+  }
   hipLaunchKernelGGL(moment_finalize_kernel, dim3(1), dim3(256), 0, st, s.partial, n_partial, style_mean,
                      s.mean, d, ld, s.sgn, loss_out);
   LAUNCH_OK();
@@ -857,6 +902,7 @@ int strotss_moment_fwd_bwd(const float* style_mean, const float* style_cov, cons
   // column mean of dL/dcy, which is zero up to rounding because sum_i cy[i,:] = 0.
   const float a = gscale * 2.0f / ((float)n * (float)d * (float)d);
   const float b = gscale / ((float)d * (float)n);
+  if (x3) return st_moment_bwd_x3(s.Pc, n, ld, s.Tp, a, s.sgn, b, gpred, st);
   return st_moment_bwd_gemm(s.cy, n, ld, s.T, a, s.sgn, b, gpred, st);
 }
 

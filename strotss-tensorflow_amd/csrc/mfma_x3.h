@@ -14,7 +14,8 @@
 // transform, the weight pack, the feature-row pass), K-blocked so that what a workgroup stages per K-step
 // is contiguous:
 //     element (kb, plane, row, k)  at  base + ((kb * 3 + plane) * rows + row) * 32 + k      (bf16)
-// with kb = K-block of 32, plane in {h, m, l}.  A 128-row tile of one plane and one K-block is 8 KiB of
+// with kb = K-block of 32, plane in {h, m, l} (an operand whose values are exact in bf16 may carry the h plane only:
+// element (kb, row, k) at base + (kb * rows + row) * 32 + k).  A 128-row tile of one plane and one K-block is 8 KiB of
 // consecutive bytes: every staging load instruction of a wave reads 1 KiB contiguous, there is no split
 // arithmetic, no zero-select and no address arithmetic in the main loop (rows past the operand's end are
 // clamped at set-up; their products land in accumulator rows the epilogue masks).
@@ -64,23 +65,27 @@ __device__ __forceinline__ void x3_store4(__bf16* base, size_t rows, size_t row,
 // stage (s+2) % 3 (free since the barrier of step s-1), one `s_waitcnt vmcnt(12)` (tile s+1 landed, tile
 // s+2 stays in flight ACROSS the barrier) + lgkmcnt(0) + raw s_barrier in the second k-chunk, then the first
 // fragments of tile s+1.  No staging registers, no ds_write, no VALU in the loop besides 4 address adds.
-template <int B_>
+// NPB_ = planes of the B operand: 3 (general f32 values) or 1 (values exact in bf16, e.g. a sign matrix: B = h, its
+// m and l planes would be zero -- three partial products instead of six, a quarter of the B bytes).
+template <int B_, int NPB_ = 3>
 struct X3Cfg {               // square block tile B x B, B = 128 (64 x 64 per wave) or 64 (32 x 32 per wave)
   static_assert(B_ == 128 || B_ == 64, "x3 main loop: 128 x 128 or 64 x 64 tiles");
+  static_assert(NPB_ == 3 || (NPB_ == 1 && B_ == 128), "single-plane B: 128 x 128 tiles only");
+  static constexpr int NPB = NPB_, NPROD = NPB_ == 3 ? 6 : 3;
   static constexpr int BM = B_, BN = B_, WM = 2, WN = 2, NT = 256;
   static constexpr int T = B_ / 64;                      // 32x32 MFMA tiles per wave and dimension
   static constexpr int TM = T, TN = T;
   static constexpr int PL = B_ * 64;                     // bytes of one plane image ([B rows][64 B])
-  static constexpr int STAGE = 6 * PL;                   // 48 KiB | 24 KiB
+  static constexpr int STAGE = (3 + NPB_) * PL;          // 48 KiB | 24 KiB (three B planes)
   static constexpr int LDS_BYTES = 3 * STAGE;            // 144 KiB (one workgroup per CU) | 72 KiB (two)
   static constexpr int G = B_ / 64;                      // 16-row DMA groups per wave, operand and plane
-  static constexpr int NP = 6 * G;                       // DMA pieces (1 KiB wave instructions) per wave and K-step
+  static constexpr int NP = (3 + NPB_) * G;              // DMA pieces (1 KiB wave instructions) per wave and K-step
 };
 
 #define X3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int G>
-struct X3Operand {          // one x3 panel operand as seen by one wave's DMA lanes
+template <int G, int NPL = 3>
+struct X3Operand {          // one x3 panel operand (NPL planes per K-block) as seen by one wave's DMA lanes
   const char* base;          // batch base, bytes
   unsigned off[G];           // byte offset of this lane's 16-byte source chunk within a plane panel, per row group
   unsigned plane;            // bytes per plane panel (rows * 64)
@@ -102,32 +107,35 @@ struct X3Operand {          // one x3 panel operand as seen by one wave's DMA la
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
   }
-  __device__ __forceinline__ void advance() { cur += 3 * plane; }
+  __device__ __forceinline__ void advance() { cur += NPL * plane; }
 };
 
 template <class Cfg>
-__device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Operand<Cfg::G>& oa, X3Operand<Cfg::G>& ob,
-                                            f32x16 (&acc)[Cfg::T][Cfg::T]) {
+__device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Operand<Cfg::G, 3>& oa,
+                                            X3Operand<Cfg::G, Cfg::NPB>& ob, f32x16 (&acc)[Cfg::T][Cfg::T]) {
   constexpr int PL = Cfg::PL, STAGE = Cfg::STAGE, T = Cfg::T, G = Cfg::G, NP = Cfg::NP, HALF = Cfg::BM / 2;
+  constexpr int NPB = Cfg::NPB, NPROD = Cfg::NPROD;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
-  // DMA piece j of a K-step (NP per wave): operand j / (3 G), plane (j % (3 G)) / G, row group j % G
+  // DMA piece j of a K-step (NP per wave): A planes first (3 G pieces), then B's; row group j % G
   auto dma_piece = [&](int j, unsigned char* stage) {
-    const int op = j / (3 * G), pl = (j % (3 * G)) / G, g = j % G;
-    unsigned char* dst = stage + (op * 3 + pl) * PL + (G * wave + g) * 1024;
-    if (op == 0) oa.dma(pl, g, dst); else ob.dma(pl, g, dst);
+    const int pl = j / G, g = j % G;                 // pl 0..2: A planes, 3..: B planes
+    unsigned char* dst = stage + pl * PL + (G * wave + g) * 1024;
+    if (pl < 3) oa.dma(pl, g, dst); else ob.dma(pl - 3, g, dst);
   };
   auto dma_tile = [&](unsigned char* stage) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) dma_piece(j, stage);
     oa.advance(); ob.advance();
   };
-  auto wait_one_tile_in_flight = [&]() { if constexpr (NP == 12) X3_WAIT_VM(12); else X3_WAIT_VM(6); };
+  auto wait_one_tile_in_flight = [&]() {
+    if constexpr (NP == 12) X3_WAIT_VM(12); else if constexpr (NP == 8) X3_WAIT_VM(8); else X3_WAIT_VM(6);
+  };
   // fragment read offsets within a stage: row-major 64-byte rows, slot = (2 kc + hh) ^ ((row >> 2) & 3)
   const int f = (l31 >> 2) & 3;
   const int a_rd = (wm * HALF + l31) * 64 + ((hh ^ f) << 4);              // kc = 0; kc = 1 is this ^ 32
   const int b_rd = 3 * PL + (wn * HALF + l31) * 64 + ((hh ^ f) << 4);
-  bf16x8 fa[2][3][T], fb[2][3][T];
+  bf16x8 fa[2][3][T], fb[2][NPB][T];
   auto read_frags = [&](const unsigned char* stage, int kc, int slot) {
     const unsigned char* pa = stage + (a_rd ^ (kc << 5));
     const unsigned char* pb = stage + (b_rd ^ (kc << 5));
@@ -136,12 +144,15 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
 #pragma unroll
       for (int i = 0; i < T; ++i) {
         fa[slot][p][i] = *reinterpret_cast<const bf16x8*>(pa + p * PL + i * 2048);
-        fb[slot][p][i] = *reinterpret_cast<const bf16x8*>(pb + p * PL + i * 2048);
+        if (p < NPB) fb[slot][p][i] = *reinterpret_cast<const bf16x8*>(pb + p * PL + i * 2048);
       }
     }
   };
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};     // partial products (A plane, B plane), smallest terms first
-  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  // partial products (A plane, B plane), smallest terms first; single-plane B: (l, h), (m, h), (h, h)
+  constexpr int PA[6] = {2, NPB == 3 ? 0 : 1, NPB == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int PB[6] = {0, NPB == 3 ? 2 : 0, NPB == 3 ? 1 : 0, 0, 1, 0};
+  constexpr int STRIDE = NPROD * T * T / NP;      // one DMA piece behind every STRIDE MFMAs of the first k-chunk
+  static_assert(STRIDE >= 1, "more DMA pieces than MFMAs in a k-chunk");
 
   unsigned char* s_cur = lds;
   unsigned char* s_nxt = lds + STAGE;
@@ -157,7 +168,7 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
+      for (int q = 0; q < NPROD; ++q) {
         if (c == 0 && q == 1) {          // second k-chunk's fragments: behind the first product group
           __builtin_amdgcn_sched_barrier(0);
           read_frags(s_cur, 1, 1);
@@ -166,12 +177,14 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
 #pragma unroll
         for (int im = 0; im < T; ++im) {
 #pragma unroll
-          for (int in_ = 0; in_ < T; ++in_)
+          for (int in_ = 0; in_ < T; ++in_) {
             acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][PA[q]][im], fb[c][PB[q]][in_], acc[im][in_], 0, 0, 0);
-          if (MODE == 2 && c == 0) {     // one DMA piece behind every T MFMAs: NP = 6 T pieces over the 6 T groups
-            __builtin_amdgcn_sched_barrier(0);
-            dma_piece(T * q + im, s_nn);
-            __builtin_amdgcn_sched_barrier(0);
+            const int done = (q * T + im) * T + in_ + 1;       // MFMAs issued in this k-chunk
+            if (MODE == 2 && c == 0 && done % STRIDE == 0 && done / STRIDE <= NP) {
+              __builtin_amdgcn_sched_barrier(0);
+              dma_piece(done / STRIDE - 1, s_nn);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
         if (c == 1 && q == 0 && MODE != 0) {
@@ -209,10 +222,13 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
   epi.set_batch(bz);
   const int m0 = (rem / gx) * Cfg::BM, n0 = (rem % gx) * Cfg::BN;
   if constexpr (Epi::SYMM) {
-    if (epi.symm && n0 < m0) return;                // mirrored by the tile above the diagonal
+    if (epi.symm && n0 < m0) {                      // mirrored by the tile above the diagonal
+      epi.finish(reinterpret_cast<float*>(lds), 0.f);
+      return;
+    }
   }
-  X3Operand<Cfg::G> oa(A + (long long)bz * strideA, M, m0);
-  X3Operand<Cfg::G> ob(B + (long long)bz * strideB, N, n0);
+  X3Operand<Cfg::G, 3> oa(A + (long long)bz * strideA, M, m0);
+  X3Operand<Cfg::G, Cfg::NPB> ob(B + (long long)bz * strideB, N, n0);
   f32x16 acc[Cfg::T][Cfg::T];
 #pragma unroll
   for (int i = 0; i < Cfg::T; ++i)

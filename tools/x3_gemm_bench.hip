@@ -9,8 +9,14 @@
 
 #include "../strotss-tensorflow_amd/csrc/mfma_x3.h"
 
+#ifndef SYMM_SKIP
+#define SYMM_SKIP 0
+#endif
 struct EpiStore {
-  static constexpr bool SYMM = false;
+  static constexpr bool SYMM = SYMM_SKIP != 0;      // SYMM_SKIP: tiles below the diagonal return at once (timing experiment)
+  static constexpr int symm = 1;
+  __device__ __forceinline__ float value(int, int, float v) const { return v; }
+  __device__ __forceinline__ void mirror(int r, int c, float v) const { C[(size_t)r * ldc + c] = v; }
   float* C; int ldc; int M, N; long long strideC;
   __device__ __forceinline__ void set_batch(int z) { C += (long long)z * strideC; }
   __device__ __forceinline__ float apply(int r, int c, float v) const {

@@ -106,6 +106,7 @@ struct EpiMomentFwd {
 struct EpiSelfsimBwd {
   static constexpr bool SYMM = false;
   const float* x; const float* r; const float* q; float* dx; int ld; int M, N; float g;
+  __device__ __forceinline__ void set_batch(int) {}
   __device__ __forceinline__ float apply(int row, int c, float v) const {
     if (row < M && c < N) {
       const size_t o = (size_t)row * ld + c;
@@ -389,6 +390,16 @@ int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long lon
   ST_LAUNCH_RET();
 }
 
+struct EpiSelfsimBwdX3 : EpiSelfsimBwd {   // branch-free loads, as EpiMomentFwdX3
+  __device__ __forceinline__ float apply(int row, int c, float v) const {
+    const int rr = min(row, M - 1);
+    const size_t o = (size_t)rr * ld + min(c, N - 1);
+    const float ri = r[rr];
+    const float out = dx[o] + g * ri * (v - x[o] * ri * q[rr]);
+    if (row < M && c < N) dx[o] = out;
+    return 0.f;
+  }
+};
 struct EpiAxpbyBiasX3 : EpiAxpbyBias {   // as EpiAxpbyBias with independent, unconditional loads (see EpiMomentFwdX3)
   __device__ __forceinline__ float apply(int r, int c, float v) const {
     float* p = &C[(size_t)min(r, M - 1) * ldc + min(c, N - 1)];
@@ -481,8 +492,8 @@ int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp
   using Cfg = X3Cfg<128>;
   EpiMomentFwdX3 e{Sx, (__bf16*)Tp, ld, ld, ld, inv_n, partial};
   const int g = cdiv(ld, 128);
-  *n_partial = g * g;
-  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiMomentFwdX3, X3MomentStore<Cfg>>), dim3(g * g), dim3(Cfg::NT), 0, s,
+  *n_partial = g * (g + 1) / 2;                      // upper-triangular launch: 171 workgroups at ld = 2208, one round
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiMomentFwdX3, X3MomentStore<Cfg>>), dim3(g * (g + 1) / 2), dim3(Cfg::NT), 0, s,
                      (const __bf16*)Pt, ld, 0LL, (const __bf16*)Pt, ld, 0LL, npad, e, X3MomentStore<Cfg>{});
   ST_LAUNCH_RET();
 }
@@ -499,12 +510,24 @@ int st_moment_bwd_x3(const void* Pc, int n, int ld, const void* Tp, float alpha,
   ST_LAUNCH_RET();
 }
 
+// dX(n x ld) += g * r_i (Mq(n x kpad) @ X(kpad x ld) - xhat q): Mq and X^T as x3 panels (rows n / rows ld, K = kpad)
+int st_selfsim_bwd_x3(const void* Mp, int kpad, const void* Xt, const float* x, const float* r, const float* q, int n,
+                      int ld, float g, float* dx, hipStream_t s) {
+  using Cfg = X3Cfg<128>;
+  EpiSelfsimBwdX3 e{{x, r, q, dx, ld, n, ld, g}};
+  dim3 grid((unsigned)cdiv(ld, 128) * cdiv(n, 128));
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiSelfsimBwdX3, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)Mp, n, 0LL,
+                     (const __bf16*)Xt, ld, 0LL, kpad, e, X3NoMirror{});
+  ST_LAUNCH_RET();
+}
+
 // st_cosine_distance on x3 panels of x and y (64 x 64 tiles: 256 workgroups at 1024 x 1024, two per CU).
 int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* yp, const float* ry, int ny, int K,
                           int symm, float* C, int ldc, hipStream_t s) {
   using Cfg = X3Cfg<64>;
   EpiCosDistX3 e{{rx, ry, C, ldc, nx, ny, symm}};
-  dim3 grid((unsigned)cdiv(ny, 64) * cdiv(nx, 64));
+  const unsigned g = cdiv(nx, 64);
+  dim3 grid(symm ? g * (g + 1) / 2 : (unsigned)cdiv(ny, 64) * g);
   hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiCosDistX3, X3Mirror<Cfg>>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)xp, nx,
                      0LL, (const __bf16*)yp, ny, 0LL, K, e, X3Mirror<Cfg>{});
   ST_LAUNCH_RET();

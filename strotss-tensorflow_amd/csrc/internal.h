@@ -28,6 +28,8 @@ int st_x3_split_rows(const float* x, int rows, int ld, int K, long long stride_i
                      hipStream_t s);
 int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* yp, const float* ry, int ny, int K,
                           int symm, float* C, int ldc, hipStream_t s);
+int st_selfsim_bwd_x3(const void* Mp, int kpad, const void* Xt, const float* x, const float* r, const float* q, int n,
+                      int ld, float g, float* dx, hipStream_t s);
 int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
                      int* n_partial, hipStream_t s);
 int st_moment_bwd_x3(const void* Pc, int n, int ld, const void* Tp, float alpha, const float* bias, float bias_scale,

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void selfsim_sym_kernel(const float* __restric
                                                           const float* __restrict__ Dx,
                                                           const float* __restrict__ r, int n, int ldc,
                                                           int kpad, float* __restrict__ Mq,
-                                                          float* __restrict__ qdot) {
+                                                          float* __restrict__ qdot, __bf16* __restrict__ Mp) {
+  // Mp != NULL: Mq goes out as x3 panels (rows = n, K = kpad; mfma_x3.h) for the bf16x3 backward GEMM instead
   __shared__ float red[4];
   const int i = blockIdx.x;
   float acc = 0.f;
@@ -106,7 +107,15 @@ __global__ __launch_bounds__(256) void selfsim_sym_kernel(const float* __restric
       acc += m * (1.0f - Dx[(size_t)i * ldc + j]);
       out = m * r[j];
     }
-    Mq[(size_t)i * ldc + j] = out;
+    if (Mp) {
+      const __bf16 h = (__bf16)out;
+      const float r1 = out - (float)h;
+      const __bf16 mm = (__bf16)r1;
+      const size_t o = ((size_t)(j >> 5) * 3 * n + i) * 32 + (j & 31);
+      Mp[o] = h; Mp[o + (size_t)n * 32] = mm; Mp[o + (size_t)2 * n * 32] = (__bf16)(r1 - (float)mm);
+    } else {
+      Mq[(size_t)i * ldc + j] = out;
+    }
   }
   acc = block_sum_256(acc, red);
   if (threadIdx.x == 0) qdot[i] = acc;
@@ -390,6 +399,7 @@ __global__ __launch_bounds__(256) void center_kernel(const float* __restrict__ y
 // The centred rows as x3 panels (mfma_x3.h) for the bf16x3 moment GEMMs, both ways round: Pc (rows = samples i < n,
 // K = ld features: the backward product's A) and Pt (rows = ld features, K = npad samples, zeros for i >= n: both
 // operands of the covariance).  One 32 x 32 tile per workgroup, transposed through LDS; grid (ld/32, npad/32).
+// mean == NULL: no centring; Pc == NULL: transposed panels only (the self-similarity backward's B operand).
 __global__ __launch_bounds__(256) void center_x3_kernel(const float* __restrict__ y, int n, int npad, int ld,
                                                         const float* __restrict__ mean, __bf16* __restrict__ Pc,
                                                         __bf16* __restrict__ Pt) {
@@ -400,8 +410,9 @@ __global__ __launch_bounds__(256) void center_x3_kernel(const float* __restrict_
     const int i = i0 + il, j = j0 + 4 * j4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (i < n) {
-      v = *reinterpret_cast<const f32x4*>(y + (size_t)i * ld + j) - *reinterpret_cast<const f32x4*>(mean + j);
-      x3_store4(Pc, n, i, j, v);
+      v = *reinterpret_cast<const f32x4*>(y + (size_t)i * ld + j);
+      if (mean) v = v - *reinterpret_cast<const f32x4*>(mean + j);
+      if (Pc) x3_store4(Pc, n, i, j, v);
     }
     tile[il][4 * j4 + 0] = v[0]; tile[il][4 * j4 + 1] = v[1]; tile[il][4 * j4 + 2] = v[2]; tile[il][4 * j4 + 3] = v[3];
   }
@@ -574,10 +585,12 @@ bool cost_x3() {
 struct SelfsimWs {
   float *rp, *rc, *Dx, *Dy, *sx, *sy, *Q, *Mq, *qdot, *lossrow;
   __bf16 *xp, *xc;               // x3 panels of pred / content (ld > 0)
+  __bf16 *xt, *mp;               // x3 panels of pred transposed (rows = ld, K = ldc) and of Mq (rows = n, K = ldc)
   int ldc;
   bool plan(Workspace& w, int n, int ld) {
     ldc = round_up(n, 32);
     xp = w.take<__bf16>((size_t)3 * n * ld); xc = w.take<__bf16>((size_t)3 * n * ld);
+    xt = w.take<__bf16>((size_t)3 * ld * ldc); mp = w.take<__bf16>((size_t)3 * n * ldc);
     rp = w.take<float>(ldc); rc = w.take<float>(ldc);
     Dx = w.take<float>((size_t)n * ldc); Dy = w.take<float>((size_t)n * ldc);
     sx = w.take<float>(ldc); sy = w.take<float>(ldc);
@@ -708,10 +721,15 @@ int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int 
   // loss = mean(|A-B|) * n = (1/n) sum |A-B|  ->  dL/dA = sign/n
   hipLaunchKernelGGL(selfsim_rowpass_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, n, ldc,
                      1.0f / (float)n, s.Q, s.lossrow);
+  const bool bx3 = cost_x3();
   hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st, s.Q, s.Dx, s.rp, n, ldc, ldc, s.Mq,
-                     s.qdot);
+                     s.qdot, bx3 ? s.mp : (__bf16*)nullptr);
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, s.lossrow, n, 1.0f / (float)n, loss_out);
+  if (bx3)
+    hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, ldc / 32), dim3(256), 0, st, pred, n, ldc, ld, (const float*)nullptr,
+                       (__bf16*)nullptr, s.xt);
   LAUNCH_OK();
+  if (bx3) return st_selfsim_bwd_x3(s.mp, ldc, s.xt, pred, s.rp, s.qdot, n, ld, gscale, gpred, st);
   return st_selfsim_bwd_gemm(s.Mq, ldc, ldc, pred, pred, s.rp, s.qdot, n, ld, gscale, gpred, st);
 }
 

@@ -209,24 +209,32 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
 
 // C[z] (M x N) = A[z] B[z]^T on x3 panels; 1-D launch of cdiv(M,B) * cdiv(N,B) * batch workgroups in XCD-aware
 // order (N-tile fastest, then M-tile, then batch: an XCD's 32 CUs share one batch's panels in their L2).
-// Epilogues as in gemm.hip (apply / finish; SYMM epilogues also value / mirror and a run-time `symm` switch:
-// tiles below the diagonal are skipped and written as the transpose of the tile above, bitwise symmetric).
+// Epilogues as in gemm.hip (apply / finish; SYMM epilogues also value / mirror and a run-time `symm` switch: then
+// the LAUNCH holds only the tiles on or above the diagonal, gx (gx + 1) / 2 workgroups, and every tile below is
+// written as the transpose of the one above, bitwise symmetric).
 template <class Cfg, class Epi, class Mirror>
 __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restrict__ A, int M, long long strideA,
                                                           const __bf16* __restrict__ B, int N, long long strideB,
                                                           int K, Epi epi, Mirror mirror) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDS_BYTES];
   const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
-  const unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const unsigned bz = tile / (gx * gy), rem = tile - bz * (gx * gy);
-  epi.set_batch(bz);
-  const int m0 = (rem / gx) * Cfg::BM, n0 = (rem % gx) * Cfg::BN;
-  if constexpr (Epi::SYMM) {
-    if (epi.symm && n0 < m0) {                      // mirrored by the tile above the diagonal
-      epi.finish(reinterpret_cast<float*>(lds), 0.f);
-      return;
-    }
+  unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  unsigned bz = 0;
+  int m0, n0;
+  bool tri = false;
+  if constexpr (Epi::SYMM) tri = epi.symm != 0;
+  if (tri) {
+    // symmetric product (M == N, one batch): the launch holds only the gx (gx + 1) / 2 tiles on or above the diagonal,
+    // enumerated row by row -- tile row i = tiles (i, i .. gx - 1)
+    unsigned i = 0, len = gx;
+    while (tile >= len) { tile -= len; --len; ++i; }
+    m0 = i * Cfg::BM; n0 = (i + tile) * Cfg::BN;
+  } else {
+    bz = tile / (gx * gy);
+    const unsigned rem = tile - bz * (gx * gy);
+    m0 = (rem / gx) * Cfg::BM; n0 = (rem % gx) * Cfg::BN;
   }
+  epi.set_batch(bz);
   X3Operand<Cfg::G, 3> oa(A + (long long)bz * strideA, M, m0);
   X3Operand<Cfg::G, Cfg::NPB> ob(B + (long long)bz * strideB, N, n0);
   f32x16 acc[Cfg::T][Cfg::T];

@@ -57,7 +57,8 @@ int main(int argc, char** argv) {
     __device__ void operator()(const EpiStore&, float*, int, int, int, int, f32x16 (&)[Cfg::T][Cfg::T], const PipeAccMap<Cfg>&) const {}
   };
   EpiStore e{dC, N, M, N, (long long)M * N};
-  dim3 grid((unsigned)(((M + TILE - 1) / TILE) * ((N + TILE - 1) / TILE) * batch));
+  const unsigned gt = (M + TILE - 1) / TILE;
+  dim3 grid(SYMM_SKIP ? gt * (gt + 1) / 2 : (unsigned)(gt * ((N + TILE - 1) / TILE) * batch));
   auto run = [&]() {
     hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiStore, NoMirror>), grid, dim3(256), 0, st, pA, M, (long long)3 * M * K, pB, N,
                        (long long)3 * N * K, K, e, NoMirror{});

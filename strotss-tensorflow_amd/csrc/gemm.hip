@@ -487,6 +487,30 @@ struct X3MomentStore {
   }
 };
 
+// C(ld x ld) = alpha * c^T c from the transposed x3 panels: the style covariance, by the SAME main loop, tile shape and
+// product order as st_moment_fwd_x3, so that moment_matching(x, x) is exactly zero.
+struct EpiSymScaleX3 {
+  static constexpr bool SYMM = true;
+  static constexpr int symm = 1;
+  float* C; int ld; int M, N; float alpha;
+  __device__ __forceinline__ void set_batch(int) {}
+  __device__ __forceinline__ float value(int, int, float v) const { return alpha * v; }
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    if (r < M && c < N && r <= c) C[(size_t)r * ld + c] = alpha * v;
+    return 0.f;
+  }
+  __device__ __forceinline__ void mirror(int r, int c, float val) const { C[(size_t)r * ld + c] = val; }
+  __device__ __forceinline__ void finish(float*, float) const {}
+};
+int st_gram_tn_x3(const void* Pt, int npad, int ld, float alpha, float* C, hipStream_t s) {
+  using Cfg = X3Cfg<128>;
+  EpiSymScaleX3 e{C, ld, ld, ld, alpha};
+  const int g = cdiv(ld, 128);
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiSymScaleX3, X3Mirror<Cfg>>), dim3(g * (g + 1) / 2), dim3(Cfg::NT), 0, s,
+                     (const __bf16*)Pt, ld, 0LL, (const __bf16*)Pt, ld, 0LL, npad, e, X3Mirror<Cfg>{});
+  ST_LAUNCH_RET();
+}
+
 int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
                      int* n_partial, hipStream_t s) {
   using Cfg = X3Cfg<128>;

@@ -30,6 +30,7 @@ int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* y
                           int symm, float* C, int ldc, hipStream_t s);
 int st_selfsim_bwd_x3(const void* Mp, int kpad, const void* Xt, const float* x, const float* r, const float* q, int n,
                       int ld, float g, float* dx, hipStream_t s);
+int st_gram_tn_x3(const void* Pt, int npad, int ld, float alpha, float* C, hipStream_t s);
 int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
                      int* n_partial, hipStream_t s);
 int st_moment_bwd_x3(const void* Pc, int n, int ld, const void* Tp, float alpha, const float* bias, float bias_scale,

@@ -882,6 +882,12 @@ int strotss_moment_stats(const float* x, int n, int d, int ld, float* mean_out, 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(ld, 64), COL_CHUNKS), dim3(256), 0, st, x, n, ld, s.psum);
   hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, st, s.psum, n, ld, mean_out);
+  if (moment_x3()) {      // same GEMM core as the prediction side (strotss_moment_fwd_bwd): identical statistics, bit for bit
+    hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, s.rows / 32), dim3(256), 0, st, x, n, s.rows, ld,
+                       (const float*)mean_out, (__bf16*)nullptr, s.Pt);
+    LAUNCH_OK();
+    return st_gram_tn_x3(s.Pt, s.rows, ld, 1.0f / (float)n, cov_out, st);
+  }
   hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st, x,
                      n, s.rows, ld, mean_out, s.cy);
   LAUNCH_OK();

@@ -189,6 +189,22 @@ def pmc_traffic(path=os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.c
     return total / launches if launches else None
 
 
+def pmc_traffic_pairwise(path=os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.csv")):
+    """Fabric bytes (FETCH_SIZE x2 + WRITE_SIZE, same passes as pmc_traffic) of one full 1024 x 1024 cosine cost-matrix
+    launch on the bf16x3 core (grid 256 workgroups x 256 threads = the style x prediction matrix).  Algorithmic: 2 x
+    13.6 MB of x3 panels + 4.2 MB out; every XCD streams the whole B panel through its own L2."""
+    import csv
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rd = csv.reader(f)
+        next(rd)
+        for name, grid, _n, r_mb, w_mb in rd:
+            if name.startswith("gemm_x3_kernel<X3Cfg<64") and "EpiCosDistX3" in name and int(grid) == 65536:
+                return (float(r_mb) + float(w_mb)) * 1e6
+    return None
+
+
 def wall_clock_to_output(dev, size=1024, level=5, max_iter=200):
     """The reference's Timer scope (run_strotss.py:44-45,159): model build + image load + all scales + postprocess
     + JPEG write, through the CLI's run() on a synthetic `size`-px pair written to a temporary directory."""
@@ -367,6 +383,8 @@ def main():
                                "launches_per_step": conv_launches,
                                "avg_launch_ms": round(conv_ms / conv_launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
             out["roofline_pairwise"] = pairwise_roofline(dev)
+            if out["roofline_pairwise"].get("executed_bf16_tflops"):
+                out["roofline_pairwise"]["traffic"] = pmc_traffic_pairwise()
             out["kernel_families_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(fam.items())}
     if rank == 0 and not args.no_pyramid and world == 1:
         del eng

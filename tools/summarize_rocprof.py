@@ -15,7 +15,7 @@ import statistics
 import sys
 from collections import defaultdict
 
-MFMA = ("conv3x3_mfma", "gemm_kc_pipe", "gemm_kernel", "gemm_split", "conv3x3_c3_fwd_mfma", "winograd43_fused")
+MFMA = ("conv3x3_mfma", "gemm_kc_pipe", "gemm_kernel", "gemm_x3", "conv3x3_c3_fwd_mfma", "winograd43_fused")
 
 
 def short(name: str) -> str:

@@ -47,6 +47,8 @@ struct EpiCosDist {  // C = 1 - acc * (ra[i]*rb[j])      (losses.py:12-15)
 // symmetry is made exact by construction: only entries on or above the diagonal are stored by their owner, every
 // entry below is the mirrored copy of its transpose (diagonal tiles mirror their own strict upper triangle).
 struct EpiCosDistX3 : EpiCosDist {
+  long long rstride, cstride;               // batch z: norms at ra/rb + z * rstride, matrix at C + z * cstride
+  __device__ __forceinline__ void set_batch(int z) { ra += z * rstride; rb += z * rstride; C += z * cstride; }
   __device__ __forceinline__ float value(int r, int c, float v) const {     // unconditional loads (clamped addresses)
     return 1.0f - v * (ra[min(r, M - 1)] * rb[min(c, N - 1)]);
   }
@@ -545,14 +547,16 @@ int st_selfsim_bwd_x3(const void* Mp, int kpad, const void* Xt, const float* x, 
   ST_LAUNCH_RET();
 }
 
-// st_cosine_distance on x3 panels of x and y (64 x 64 tiles: 256 workgroups at 1024 x 1024, two per CU).
+// st_cosine_distance on x3 panels of x and y (64 x 64 tiles: 256 workgroups at 1024 x 1024, two per CU).  batch > 1:
+// further matrices of the same shape at panel / norm / output strides (elements): symmetric pairs share one launch.
 int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* yp, const float* ry, int ny, int K,
-                          int symm, float* C, int ldc, hipStream_t s) {
+                          int symm, float* C, int ldc, int batch, long long pstride, long long rstride,
+                          long long cstride, hipStream_t s) {
   using Cfg = X3Cfg<64>;
-  EpiCosDistX3 e{{rx, ry, C, ldc, nx, ny, symm}};
+  EpiCosDistX3 e{{rx, ry, C, ldc, nx, ny, symm}, rstride, cstride};
   const unsigned g = cdiv(nx, 64);
-  dim3 grid(symm ? g * (g + 1) / 2 : (unsigned)cdiv(ny, 64) * g);
+  dim3 grid((symm ? g * (g + 1) / 2 : (unsigned)cdiv(ny, 64) * g) * batch);
   hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiCosDistX3, X3Mirror<Cfg>>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)xp, nx,
-                     0LL, (const __bf16*)yp, ny, 0LL, K, e, X3Mirror<Cfg>{});
+                     pstride, (const __bf16*)yp, ny, pstride, K, e, X3Mirror<Cfg>{});
   ST_LAUNCH_RET();
 }

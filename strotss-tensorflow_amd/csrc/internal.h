@@ -27,7 +27,8 @@ int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned c
 int st_x3_split_rows(const float* x, int rows, int ld, int K, long long stride_in, void* panels, int batch,
                      hipStream_t s);
 int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* yp, const float* ry, int ny, int K,
-                          int symm, float* C, int ldc, hipStream_t s);
+                          int symm, float* C, int ldc, int batch, long long pstride, long long rstride,
+                          long long cstride, hipStream_t s);
 int st_selfsim_bwd_x3(const void* Mp, int kpad, const void* Xt, const float* x, const float* r, const float* q, int n,
                       int ld, float g, float* dx, hipStream_t s);
 int st_gram_tn_x3(const void* Pt, int npad, int ld, float alpha, float* C, hipStream_t s);

@@ -26,8 +26,12 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restri
 
 // The same pass also writing the row as x3 panels (mfma_x3.h: three bf16 planes per value, K-blocked) for the
 // bf16x3 cost-matrix GEMM.  r may be NULL (norms already known).  ld % 32 == 0.
+// blockIdx.y = 1 selects a second matrix (x1, n1, r1, panels1): both feature matrices of a loss in one launch.
 __global__ __launch_bounds__(256) void row_inv_norm_x3_kernel(const float* __restrict__ x, int n, int ld,
-                                                              float* __restrict__ r, __bf16* __restrict__ panels) {
+                                                              float* __restrict__ r, __bf16* __restrict__ panels,
+                                                              const float* __restrict__ x1, int n1,
+                                                              float* __restrict__ r1, __bf16* __restrict__ panels1) {
+  if (blockIdx.y) { x = x1; n = n1; r = r1; panels = panels1; }
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -46,8 +50,10 @@ __global__ __launch_bounds__(256) void row_inv_norm_x3_kernel(const float* __res
 
 // s[i] = sum_{j<n} D[i,j]
 __global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ D, int n, int ldc,
-                                                      float* __restrict__ s) {
+                                                      float* __restrict__ s, const float* __restrict__ D1,
+                                                      float* __restrict__ s1) {
   __shared__ float red[4];
+  if (blockIdx.y) { D = D1; s = s1; }                  // second matrix of the same shape
   const float* p = D + (size_t)blockIdx.x * ldc;
   float a = 0.f;
   for (int j = threadIdx.x; j < n; j += 256) a += p[j];
@@ -273,7 +279,10 @@ __global__ __launch_bounds__(256) void remd_cos_bwd_kernel(
 // ---------------------------------------------------------------- palette (D = 3, pure VALU)
 // yuv[i] = (Y, U, V, r) with r the inverse norm of the YUV vector  (strotss_utils.py:166-167)
 __global__ __launch_bounds__(256) void palette_prepare_kernel(const float* __restrict__ feat, int n, int ld,
-                                                              f32x4* __restrict__ yuv, int convert) {
+                                                              f32x4* __restrict__ yuv, int convert,
+                                                              const float* __restrict__ feat1, int n1,
+                                                              f32x4* __restrict__ yuv1) {
+  if (blockIdx.y) { feat = feat1; n = n1; yuv = yuv1; }    // second matrix (style and prediction in one launch)
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float* p = feat + (size_t)i * ld;
@@ -674,7 +683,7 @@ int strotss_row_inv_norm_x3(const float* x, int n, int ld, float* r, void* panel
   ST_CHECK_ARG(x && panels && n > 0 && ld > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
   hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, n, ld, r,
-                     (__bf16*)panels);
+                     (__bf16*)panels, (const float*)nullptr, 0, (float*)nullptr, (__bf16*)nullptr);
   ST_LAUNCH_RET();
 }
 
@@ -682,7 +691,7 @@ int strotss_cosine_distance_x3(const void* xp, const float* rx, int nx, const vo
                                int ld, float* C, int ldc, void* stream) {
   ST_CHECK_ARG(xp && rx && yp && ry && C && nx > 0 && ny > 0 && ldc >= ny, STROTSS_EINVAL);
   ST_CHECK_ARG(ld % 32 == 0 && ld > 0, STROTSS_EALIGN);
-  return st_cosine_distance_x3(xp, rx, nx, yp, ry, ny, ld, (xp == yp && rx == ry && nx == ny) ? 1 : 0, C, ldc,
+  return st_cosine_distance_x3(xp, rx, nx, yp, ry, ny, ld, (xp == yp && rx == ry && nx == ny) ? 1 : 0, C, ldc, 1, 0, 0, 0,
                                (hipStream_t)stream);
 }
 
@@ -704,11 +713,11 @@ int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int 
   hipStream_t st = (hipStream_t)stream;
   const int ldc = s.ldc;
   if (cost_x3()) {      // cost matrices on the bf16x3 core: the norm pass also writes the rows' x3 panels
-    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp, s.xp);
-    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, content, n, ld, s.rc, s.xc);
+    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4), 2), dim3(256), 0, st, pred, n, ld, s.rp, s.xp, content, n,
+                       s.rc, s.xc);
     LAUNCH_OK();
-    CHK(st_cosine_distance_x3(s.xp, s.rp, n, s.xp, s.rp, n, ld, 1, s.Dx, ldc, st));
-    CHK(st_cosine_distance_x3(s.xc, s.rc, n, s.xc, s.rc, n, ld, 1, s.Dy, ldc, st));
+    // both symmetric matrices in ONE launch (2 x 136 upper-triangular tiles at n = 1024: one round of the 512 slots)
+    CHK(st_cosine_distance_x3(s.xp, s.rp, n, s.xp, s.rp, n, ld, 1, s.Dx, ldc, 2, s.xc - s.xp, s.rc - s.rp, s.Dy - s.Dx, st));
   } else {
     hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
     hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, content, n, ld, s.rc);
@@ -716,8 +725,7 @@ int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int 
     CHK(st_cosine_distance(pred, s.rp, n, pred, s.rp, n, ld, s.Dx, ldc, st));
     CHK(st_cosine_distance(content, s.rc, n, content, s.rc, n, ld, s.Dy, ldc, st));
   }
-  hipLaunchKernelGGL(row_sum_kernel, dim3(n), dim3(256), 0, st, s.Dx, n, ldc, s.sx);
-  hipLaunchKernelGGL(row_sum_kernel, dim3(n), dim3(256), 0, st, s.Dy, n, ldc, s.sy);
+  hipLaunchKernelGGL(row_sum_kernel, dim3(n, 2), dim3(256), 0, st, s.Dx, n, ldc, s.sx, s.Dy, s.sy);
   // loss = mean(|A-B|) * n = (1/n) sum |A-B|  ->  dL/dA = sign/n
   hipLaunchKernelGGL(selfsim_rowpass_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, n, ldc,
                      1.0f / (float)n, s.Q, s.lossrow);
@@ -818,8 +826,8 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   const int ldc = s.ldc;
   const bool x3 = cost_x3();
   if (x3) {
-    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp, s.xp);
-    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(ns, 4)), dim3(256), 0, st, style, ns, ld, (float*)nullptr, s.xs);
+    hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n > ns ? n : ns, 4), 2), dim3(256), 0, st, pred, n, ld, s.rp, s.xp,
+                       style, ns, (float*)nullptr, s.xs);
   } else {
     hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
   }
@@ -828,7 +836,7 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   // order), so that the backward kernel's scans of "column j" are contiguous: minima over i per prediction row j
   // are row minima (cmin), minima over j per style row i column minima (rmin)
   const int ldt = s.ldt;
-  if (x3) CHK(st_cosine_distance_x3(s.xp, s.rp, n, s.xs, rs, ns, ld, 0, s.C, ldt, st));
+  if (x3) CHK(st_cosine_distance_x3(s.xp, s.rp, n, s.xs, rs, ns, ld, 0, s.C, ldt, 1, 0, 0, 0, st));
   else CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.C, ldt, st));
   hipLaunchKernelGGL(row_min_kernel, dim3(n), dim3(256), 0, st, s.C, ns, ldt, s.cmin, s.ccnt);
   hipLaunchKernelGGL(col_min_partial_kernel, dim3(cdiv(ns, 64), COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.pmin,
@@ -850,8 +858,8 @@ int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, 
   ST_CHECK_ARG(s.plan(w, ns, n, 0), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
   const int ldc = s.ldc;
-  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, st, style, ns, ld, s.ys, rgb_to_yuv);
-  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pred, n, ld, s.yp, rgb_to_yuv);
+  hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(n > ns ? n : ns, 256), 2), dim3(256), 0, st, style, ns, ld, s.ys,
+                     rgb_to_yuv, pred, n, s.yp);
   hipLaunchKernelGGL(palette_cost_kernel, dim3(cdiv(n, 256), ns), dim3(256), 0, st, s.ys, ns, s.yp, n, s.C,
                      ldc);
   hipLaunchKernelGGL(row_min_kernel, dim3(ns), dim3(256), 0, st, s.C, n, ldc, s.rmin, s.rcnt);

@@ -224,8 +224,11 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
   bool tri = false;
   if constexpr (Epi::SYMM) tri = epi.symm != 0;
   if (tri) {
-    // symmetric product (M == N, one batch): the launch holds only the gx (gx + 1) / 2 tiles on or above the diagonal,
-    // enumerated row by row -- tile row i = tiles (i, i .. gx - 1)
+    // symmetric product (M == N): the launch holds only the gx (gx + 1) / 2 tiles on or above the diagonal of every
+    // batch entry, enumerated row by row -- tile row i = tiles (i, i .. gx - 1)
+    const unsigned ntri = gx * (gx + 1) / 2;
+    bz = tile / ntri;
+    tile -= bz * ntri;
     unsigned i = 0, len = gx;
     while (tile >= len) { tile -= len; --len; ++i; }
     m0 = i * Cfg::BM; n0 = (i + tile) * Cfg::BN;

@@ -139,30 +139,30 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
 
 // ---------------------------------------------------------------- relaxed EMD
 // rmin[i] = min_j C[i,j], rcnt[i] = #{j : C[i,j] == rmin[i]}
-__global__ __launch_bounds__(256) void row_min_kernel(const float* __restrict__ C, int n, int ldc,
-                                                      float* __restrict__ rmin, float* __restrict__ rcnt) {
+__device__ __forceinline__ void row_min_block(const float* __restrict__ C, int row, int n, int ldc,
+                                              float* __restrict__ rmin, float* __restrict__ rcnt) {
   __shared__ float red[4];
-  const float* p = C + (size_t)blockIdx.x * ldc;
+  const float* p = C + (size_t)row * ldc;
   float m = INFINITY;
   for (int j = threadIdx.x; j < n; j += 256) m = fminf(m, p[j]);
   m = block_min_256(m, red);
   float c = 0.f;
   for (int j = threadIdx.x; j < n; j += 256) c += (p[j] == m) ? 1.f : 0.f;
   c = block_sum_256(c, red);
-  if (threadIdx.x == 0) { rmin[blockIdx.x] = m; rcnt[blockIdx.x] = c; }
+  if (threadIdx.x == 0) { rmin[row] = m; rcnt[row] = c; }
 }
 // cmin[j] = min_i C[i,j], ccnt[j] = #{i : C[i,j] == cmin[j]} in two stages so that the column reduction
 // uses the whole chip: stage 1 reduces COL_CHUNKS row chunks (grid (n/64, COL_CHUNKS)) to a local
 // (min, count-of-min) per column, stage 2 combines them (count = sum over the chunks that attain the
 // global min).  Fixed order -> bitwise reproducible.
 #define COL_CHUNKS 16
-__global__ __launch_bounds__(256) void col_min_partial_kernel(const float* __restrict__ C, int ns, int n, int ldc,
-                                                              float* __restrict__ pmin, float* __restrict__ pcnt) {
+__device__ __forceinline__ void col_min_partial_block(const float* __restrict__ C, int bx, int by, int ns, int n, int ldc,
+                                                      float* __restrict__ pmin, float* __restrict__ pcnt) {
   __shared__ float sm[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + c;
+  const int j = bx * 64 + c;
   const int per = (ns + COL_CHUNKS - 1) / COL_CHUNKS;
-  const int i0 = blockIdx.y * per, i1 = min(ns, i0 + per);
+  const int i0 = by * per, i1 = min(ns, i0 + per);
   float m = INFINITY;
   if (j < n)
     for (int i = i0 + g; i < i1; i += 4) m = fminf(m, C[(size_t)i * ldc + j]);
@@ -176,37 +176,53 @@ __global__ __launch_bounds__(256) void col_min_partial_kernel(const float* __res
   sm[g][c] = cnt;
   __syncthreads();
   if (g == 0 && j < n) {
-    pmin[(size_t)blockIdx.y * ldc + j] = m;
-    pcnt[(size_t)blockIdx.y * ldc + j] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    pmin[(size_t)by * ldc + j] = m;
+    pcnt[(size_t)by * ldc + j] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
   }
 }
-__global__ __launch_bounds__(256) void col_min_final_kernel(const float* __restrict__ pmin,
-                                                            const float* __restrict__ pcnt, int n, int ldc,
-                                                            float* __restrict__ cmin, float* __restrict__ ccnt) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  float m = INFINITY;
-#pragma unroll
-  for (int k = 0; k < COL_CHUNKS; ++k) m = fminf(m, pmin[(size_t)k * ldc + j]);
-  float cnt = 0.f;
-#pragma unroll
-  for (int k = 0; k < COL_CHUNKS; ++k) cnt += (pmin[(size_t)k * ldc + j] == m) ? pcnt[(size_t)k * ldc + j] : 0.f;
-  cmin[j] = m;
-  ccnt[j] = cnt;
+// Row minima (one workgroup per row: rows x n matrix) and stage 1 of the column minima in ONE launch:
+// workgroups [0, rows) take the rows, the following cdiv(n, 64) * COL_CHUNKS the column chunks.
+__global__ __launch_bounds__(256) void row_col_min_kernel(const float* __restrict__ C, int rows, int n, int ldc,
+                                                          float* __restrict__ rmin, float* __restrict__ rcnt,
+                                                          float* __restrict__ pmin, float* __restrict__ pcnt) {
+  const int b = blockIdx.x;
+  if (b < rows) {
+    row_min_block(C, b, n, ldc, rmin, rcnt);
+  } else {
+    const int gx = (n + 63) / 64, bb = b - rows;
+    col_min_partial_block(C, bb % gx, bb / gx, rows, n, ldc, pmin, pcnt);
+  }
 }
-// loss = max(mean rmin, mean cmin); sel[0] = 1 when the row branch carries the gradient
-// (tf.maximum: first argument on ties).
-__global__ __launch_bounds__(256) void remd_select_kernel(const float* __restrict__ rmin, int ns,
-                                                          const float* __restrict__ cmin, int n,
-                                                          float* __restrict__ loss_out, int* __restrict__ sel) {
+// Stage 2 of the column minima + the choice of the REMD branch, one workgroup:
+//   cmin[j] = min over the chunks, ccnt[j] = count of the minimum;
+//   loss = max(R_X, R_Y) with R_X = mean of `xmin` (minima per style row), R_Y = mean of the minima per prediction
+//   row; sel[0] = 1 when the R_X branch carries the gradient (tf.maximum: first argument on ties).
+// col_is_x: the column minima are the R_X side (pred-major cost matrix of the cosine REMD), else the R_Y side.
+__global__ __launch_bounds__(256) void col_min_final_select_kernel(const float* __restrict__ pmin,
+                                                                   const float* __restrict__ pcnt, int n, int ldc,
+                                                                   float* __restrict__ cmin, float* __restrict__ ccnt,
+                                                                   const float* __restrict__ rowmin, int rows,
+                                                                   int col_is_x, float* __restrict__ loss_out,
+                                                                   int* __restrict__ sel) {
   __shared__ float red[4];
   float a = 0.f, b = 0.f;
-  for (int i = threadIdx.x; i < ns; i += 256) a += rmin[i];
-  for (int i = threadIdx.x; i < n; i += 256) b += cmin[i];
+  for (int j = threadIdx.x; j < n; j += 256) {
+    float m = INFINITY;
+#pragma unroll
+    for (int k = 0; k < COL_CHUNKS; ++k) m = fminf(m, pmin[(size_t)k * ldc + j]);
+    float cnt = 0.f;
+#pragma unroll
+    for (int k = 0; k < COL_CHUNKS; ++k) cnt += (pmin[(size_t)k * ldc + j] == m) ? pcnt[(size_t)k * ldc + j] : 0.f;
+    cmin[j] = m;
+    ccnt[j] = cnt;
+    a += m;
+  }
+  for (int i = threadIdx.x; i < rows; i += 256) b += rowmin[i];
   a = block_sum_256(a, red);
   b = block_sum_256(b, red);
   if (threadIdx.x == 0) {
-    const float rx = a / (float)ns, ry = b / (float)n;
+    const float mc = a / (float)n, mr = b / (float)rows;
+    const float rx = col_is_x ? mc : mr, ry = col_is_x ? mr : mc;
     const int s = rx >= ry;
     loss_out[0] = s ? rx : ry;
     sel[0] = s;
@@ -838,12 +854,10 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   const int ldt = s.ldt;
   if (x3) CHK(st_cosine_distance_x3(s.xp, s.rp, n, s.xs, rs, ns, ld, 0, s.C, ldt, 1, 0, 0, 0, st));
   else CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.C, ldt, st));
-  hipLaunchKernelGGL(row_min_kernel, dim3(n), dim3(256), 0, st, s.C, ns, ldt, s.cmin, s.ccnt);
-  hipLaunchKernelGGL(col_min_partial_kernel, dim3(cdiv(ns, 64), COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.pmin,
-                     s.pcnt);
-  hipLaunchKernelGGL(col_min_final_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin,
-                     s.rcnt);
-  hipLaunchKernelGGL(remd_select_kernel, dim3(1), dim3(256), 0, st, s.rmin, ns, s.cmin, n, loss_out, s.sel);
+  hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.cmin,
+                     s.ccnt, s.pmin, s.pcnt);
+  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(256), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin, s.rcnt,
+                     s.cmin, n, 1, loss_out, s.sel);
   hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldt, style, rs, ns, pred, s.rp, n,
                      ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
   ST_LAUNCH_RET();
@@ -862,12 +876,10 @@ int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, 
                      rgb_to_yuv, pred, n, s.yp);
   hipLaunchKernelGGL(palette_cost_kernel, dim3(cdiv(n, 256), ns), dim3(256), 0, st, s.ys, ns, s.yp, n, s.C,
                      ldc);
-  hipLaunchKernelGGL(row_min_kernel, dim3(ns), dim3(256), 0, st, s.C, n, ldc, s.rmin, s.rcnt);
-  hipLaunchKernelGGL(col_min_partial_kernel, dim3(cdiv(n, 64), COL_CHUNKS), dim3(256), 0, st, s.C, ns, n, ldc, s.pmin,
-                     s.pcnt);
-  hipLaunchKernelGGL(col_min_final_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, s.pmin, s.pcnt, n, ldc, s.cmin,
-                     s.ccnt);
-  hipLaunchKernelGGL(remd_select_kernel, dim3(1), dim3(256), 0, st, s.rmin, ns, s.cmin, n, loss_out, s.sel);
+  hipLaunchKernelGGL(row_col_min_kernel, dim3(ns + cdiv(n, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, ns, n, ldc, s.rmin,
+                     s.rcnt, s.pmin, s.pcnt);
+  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(256), 0, st, s.pmin, s.pcnt, n, ldc, s.cmin, s.ccnt,
+                     s.rmin, ns, 0, loss_out, s.sel);
   hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, s.C, ldc, s.ys, ns, s.yp, n, s.rmin,
                      s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred, ld, rgb_to_yuv);
   ST_LAUNCH_RET();

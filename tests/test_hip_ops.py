@@ -260,7 +260,7 @@ def test_hypercol_gather_and_scatter(ops, hw):
 
 
 # ------------------------------------------------------------------ losses
-@pytest.mark.parametrize("n,d", [(48, 35), (200, 131), (64, 64), (1024, 259)])
+@pytest.mark.parametrize("n,d", [(48, 35), (200, 131), (64, 64), (1024, 259), (70, 20), (129, 96), (6, 7)])
 def test_cosine_distance_and_norms(ops, n, d):
     x = _feat(n, d, 1); y = _feat(n - 5, d, 2)
     bx, by = _fbuf(ops, x), _fbuf(ops, y)
@@ -282,7 +282,7 @@ def test_cosine_distance_and_norms(ops, n, d):
     assert (D3 - D).abs().max() < 2e-6
 
 
-@pytest.mark.parametrize("n,ns,d", [(48, 48, 35), (100, 70, 131), (256, 300, 259)])
+@pytest.mark.parametrize("n,ns,d", [(48, 48, 35), (100, 70, 131), (256, 300, 259), (40, 33, 24), (130, 129, 64)])
 def test_losses_fwd_bwd(ops, n, ns, d):
     x = _feat(ns, d, 3); y = _feat(n, d, 4); c = _feat(n, d, 5)
     bx, by, bc = _fbuf(ops, x), _fbuf(ops, y), _fbuf(ops, c)

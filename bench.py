@@ -271,9 +271,18 @@ def cpu_baseline(scale, budget_s=25.0):
         while timed < 5 and (timed == 0 or t_total + t_total / timed <= budget_s):
             t_total += one_step()
             timed += 1
-    return {"value": round(timed / t_total, 5), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"{timed} step(s) of the {scale}x{scale} scale (1024 samples) {note}, fp32 torch-CPU "
-                      f"oracle with {threads} threads (the reference pins TF to 1 thread, nn/rand.py:16-17)"}
+    out = {"value": round(timed / t_total, 5), "unit": "steps/s", "cores": threads, "kind": "port",
+           "sample": f"{timed} step(s) of the {scale}x{scale} scale (1024 samples) {note}, fp32 torch-CPU "
+                     f"oracle with {threads} threads (the reference pins TF to 1 thread, nn/rand.py:16-17)"}
+    # the reference's own setting (1 inter-op + 1 intra-op thread, nn/rand.py:16-17): ONE step of the same workload
+    # when the multi-threaded rate says it fits the budget (SURVEY.md 8d asks for both)
+    if os.environ.get("STROTSS_CPU_1THREAD", "1") != "0" and threads > 1 and threads / out["value"] <= 2.0 * budget_s:
+        torch.set_num_threads(1)
+        t1 = one_step()
+        torch.set_num_threads(threads)
+        out["one_thread"] = {"value": round(1.0 / t1, 5), "unit": "steps/s", "cores": 1,
+                             "sample": f"1 step of the {scale}x{scale} scale, no warm-up, torch.set_num_threads(1)"}
+    return out
 
 
 def main():

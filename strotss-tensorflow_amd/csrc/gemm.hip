@@ -46,7 +46,8 @@ struct EpiCosDist {  // C = 1 - acc * (ra[i]*rb[j])      (losses.py:12-15)
 // The same on the bf16x3 core.  There the partial products of (i,j) and (j,i) are accumulated in different orders, so
 // symmetry is made exact by construction: only entries on or above the diagonal are stored by their owner, every
 // entry below is the mirrored copy of its transpose (diagonal tiles mirror their own strict upper triangle).
-struct EpiCosDistX3 : EpiCosDist {
+struct EpiCosDistX3 : EpiCosDist, X3NoPrefetch<EpiCosDistX3> {
+  using X3NoPrefetch<EpiCosDistX3>::apply;
   long long rstride, cstride;               // batch z: norms at ra/rb + z * rstride, matrix at C + z * cstride
   __device__ __forceinline__ void set_batch(int z) { ra += z * rstride; rb += z * rstride; C += z * cstride; }
   __device__ __forceinline__ float value(int r, int c, float v) const {     // unconditional loads (clamped addresses)
@@ -358,14 +359,18 @@ int st_x3_split_rows(const float* x, int rows, int ld, int K, long long stride_i
   ST_LAUNCH_RET();
 }
 
+struct EpiScaleStoreX3 : EpiScaleStore, X3NoPrefetch<EpiScaleStoreX3> {
+  using EpiScaleStore::apply;
+  using X3NoPrefetch<EpiScaleStoreX3>::apply;
+};
 struct X3NoMirror {
-  template <class Epi, class Acc, class Map>
-  __device__ __forceinline__ void operator()(const Epi&, float*, int, int, int, int, Acc&, const Map&) const {}
+  template <class Epi, class Pre, class Acc, class Map>
+  __device__ __forceinline__ void operator()(const Epi&, Pre&, float*, int, int, int, int, Acc&, const Map&) const {}
 };
 template <class Cfg>
 struct X3Mirror {       // writes the transpose of the workgroup's tile through LDS (mirror_tile above)
-  template <class Epi, class Acc, class Map>
-  __device__ __forceinline__ void operator()(const Epi& epi, float* tile, int m0, int n0, int M, int N, Acc& acc,
+  template <class Epi, class Pre, class Acc, class Map>
+  __device__ __forceinline__ void operator()(const Epi& epi, Pre&, float* tile, int m0, int n0, int M, int N, Acc& acc,
                                              const Map& map) const {
     mirror_tile<Cfg::BM, Cfg::BN, Cfg::NT, true>(epi, tile, m0, n0, M, N, [&](auto put) {
 #pragma unroll
@@ -385,28 +390,40 @@ struct X3Mirror {       // writes the transpose of the workgroup's tile through 
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
                        int batch, hipStream_t s) {
   using Cfg = X3Cfg<128>;
-  EpiScaleStore e{C, ldc, M, N, 1.0f, strideC};
+  EpiScaleStoreX3 e{{C, ldc, M, N, 1.0f, strideC}, {}};
   dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
-  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStore, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
+  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStoreX3, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
                      (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e, X3NoMirror{});
   ST_LAUNCH_RET();
 }
 
-struct EpiSelfsimBwdX3 : EpiSelfsimBwd {   // branch-free loads, as EpiMomentFwdX3
-  __device__ __forceinline__ float apply(int row, int c, float v) const {
+// The two read-modify-write epilogues fetch what they need BEFORE the main loop (gemm_x3_kernel: Pre / prefetch), with
+// clamped addresses and no conditions; only the store is predicated.
+struct EpiSelfsimBwdX3 : EpiSelfsimBwd {
+  template <int T> struct Pre { float dx0[T][T][16], x0[T][T][16], ri[T][16], qi[T][16]; };
+  template <class P> __device__ __forceinline__ void prefetch(P& p, int im, int in, int reg, int row, int c) const {
     const int rr = min(row, M - 1);
     const size_t o = (size_t)rr * ld + min(c, N - 1);
-    const float ri = r[rr];
-    const float out = dx[o] + g * ri * (v - x[o] * ri * q[rr]);
-    if (row < M && c < N) dx[o] = out;
+    p.dx0[im][in][reg] = dx[o];
+    p.x0[im][in][reg] = x[o];
+    if (in == 0) { p.ri[im][reg] = r[rr]; p.qi[im][reg] = q[rr]; }
+  }
+  template <class P> __device__ __forceinline__ float apply(P& p, int im, int in, int reg, int row, int c, float v) const {
+    const float ri = p.ri[im][reg];
+    const float out = p.dx0[im][in][reg] + g * ri * (v - p.x0[im][in][reg] * ri * p.qi[im][reg]);
+    if (row < M && c < N) dx[(size_t)row * ld + c] = out;
     return 0.f;
   }
 };
-struct EpiAxpbyBiasX3 : EpiAxpbyBias {   // as EpiAxpbyBias with independent, unconditional loads (see EpiMomentFwdX3)
-  __device__ __forceinline__ float apply(int r, int c, float v) const {
-    float* p = &C[(size_t)min(r, M - 1) * ldc + min(c, N - 1)];
-    const float out = *p + alpha * v + bias_scale * bias[min(c, N - 1)];
-    if (r < M && c < N) *p = out;
+struct EpiAxpbyBiasX3 : EpiAxpbyBias {
+  template <int T> struct Pre { float c0[T][T][16], b[T]; };
+  template <class P> __device__ __forceinline__ void prefetch(P& p, int im, int in, int reg, int r, int c) const {
+    p.c0[im][in][reg] = C[(size_t)min(r, M - 1) * ldc + min(c, N - 1)];
+    if (im == 0 && reg == 0) p.b[in] = bias[min(c, N - 1)];
+  }
+  template <class P> __device__ __forceinline__ float apply(P& p, int im, int in, int reg, int r, int c, float v) const {
+    const float out = p.c0[im][in][reg] + alpha * v + bias_scale * p.b[in];
+    if (r < M && c < N) C[(size_t)r * ldc + c] = out;
     return 0.f;
   }
 };
@@ -418,14 +435,15 @@ struct EpiMomentFwdX3 {
   static constexpr int symm = 1;
   const float* Sx; __bf16* Tp; int ld; int M, N; float inv_n; float* partial;
   __device__ __forceinline__ void set_batch(int) {}
-  // Branch-free with clamped addresses: one workgroup per CU has nothing to hide a load behind, so the 64 loads of a
-  // lane must be independent and unconditional for the compiler to issue them back to back (inside `if`s they were
-  // waited for one by one: 45 us of epilogue per tile).
-  __device__ __forceinline__ float sx(int r, int c) const { return Sx[(size_t)min(r, M - 1) * ld + min(c, N - 1)]; }
-  __device__ __forceinline__ float value(int r, int c, float v) const { return signf(v * inv_n - sx(r, c)); }
+  // The style covariance entries of the tile are fetched before the main loop (clamped addresses, no conditions): one
+  // workgroup per CU has nothing to hide a load behind (inside `if`s in the epilogue they cost 45 us per tile).
+  template <int T> struct Pre { float sx[T][T][16]; };
+  template <class P> __device__ __forceinline__ void prefetch(P& p, int im, int in, int reg, int r, int c) const {
+    p.sx[im][in][reg] = Sx[(size_t)min(r, M - 1) * ld + min(c, N - 1)];
+  }
   // the owner of the upper triangle counts |diff| (twice off the diagonal); T is written by X3MomentStore below
-  __device__ __forceinline__ float apply(int r, int c, float v) const {
-    const float a = fabsf(v * inv_n - sx(r, c));
+  template <class P> __device__ __forceinline__ float apply(P& p, int im, int in, int reg, int r, int c, float v) const {
+    const float a = fabsf(v * inv_n - p.sx[im][in][reg]);
     const float w = (r < M && c < N && r <= c) ? (r == c ? 1.f : 2.f) : 0.f;
     return w * a;
   }
@@ -439,8 +457,8 @@ struct EpiMomentFwdX3 {
 // the accumulators made this kernel 2.4x slower).  Diagonal tiles are symmetrised in LDS first (upper triangle wins).
 template <class Cfg>
 struct X3MomentStore {
-  template <class Acc, class Map>
-  __device__ __forceinline__ void operator()(const EpiMomentFwdX3& epi, float* tile, int m0, int n0, int M, int N,
+  template <class Pre, class Acc, class Map>
+  __device__ __forceinline__ void operator()(const EpiMomentFwdX3& epi, Pre& pre, float* tile, int m0, int n0, int M, int N,
                                              Acc& acc, const Map& map) const {
     constexpr int B = Cfg::BM, LD = B + 1;
     __syncthreads();                                  // operands in LDS are dead
@@ -451,7 +469,7 @@ struct X3MomentStore {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int r = map.row(im, reg), c = map.colof(in);
-          tile[r * LD + c] = epi.value(m0 + r, n0 + c, acc[im][in][reg]);      // out-of-range entries are never stored
+          tile[r * LD + c] = signf(acc[im][in][reg] * epi.inv_n - pre.sx[im][in][reg]);    // out-of-range: never stored
         }
     __syncthreads();
     const bool diag = n0 == m0;
@@ -491,7 +509,8 @@ struct X3MomentStore {
 
 // C(ld x ld) = alpha * c^T c from the transposed x3 panels: the style covariance, by the SAME main loop, tile shape and
 // product order as st_moment_fwd_x3, so that moment_matching(x, x) is exactly zero.
-struct EpiSymScaleX3 {
+struct EpiSymScaleX3 : X3NoPrefetch<EpiSymScaleX3> {
+  using X3NoPrefetch<EpiSymScaleX3>::apply;
   static constexpr bool SYMM = true;
   static constexpr int symm = 1;
   float* C; int ld; int M, N; float alpha;
@@ -506,7 +525,7 @@ struct EpiSymScaleX3 {
 };
 int st_gram_tn_x3(const void* Pt, int npad, int ld, float alpha, float* C, hipStream_t s) {
   using Cfg = X3Cfg<128>;
-  EpiSymScaleX3 e{C, ld, ld, ld, alpha};
+  EpiSymScaleX3 e{{}, C, ld, ld, ld, alpha};
   const int g = cdiv(ld, 128);
   hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiSymScaleX3, X3Mirror<Cfg>>), dim3(g * (g + 1) / 2), dim3(Cfg::NT), 0, s,
                      (const __bf16*)Pt, ld, 0LL, (const __bf16*)Pt, ld, 0LL, npad, e, X3Mirror<Cfg>{});
@@ -553,7 +572,7 @@ int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* y
                           int symm, float* C, int ldc, int batch, long long pstride, long long rstride,
                           long long cstride, hipStream_t s) {
   using Cfg = X3Cfg<64>;
-  EpiCosDistX3 e{{rx, ry, C, ldc, nx, ny, symm}, rstride, cstride};
+  EpiCosDistX3 e{{rx, ry, C, ldc, nx, ny, symm}, {}, rstride, cstride};
   const unsigned g = cdiv(nx, 64);
   dim3 grid((symm ? g * (g + 1) / 2 : (unsigned)cdiv(ny, 64) * g) * batch);
   hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiCosDistX3, X3Mirror<Cfg>>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)xp, nx,

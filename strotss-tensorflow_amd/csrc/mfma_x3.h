@@ -207,6 +207,17 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
   kstep(std::integral_constant<int, 0>{});
 }
 
+// Default "no prefetch" protocol for epilogues: derive from X3NoPrefetch<Derived> (CRTP) to get Pre / prefetch / the
+// 7-argument apply forwarding to the plain apply(r, c, v).
+template <class D>
+struct X3NoPrefetch {
+  template <int T> struct Pre {};
+  template <class P> __device__ __forceinline__ void prefetch(P&, int, int, int, int, int) const {}
+  template <class P> __device__ __forceinline__ float apply(P&, int, int, int, int r, int c, float v) const {
+    return static_cast<const D*>(this)->apply(r, c, v);
+  }
+};
+
 // C[z] (M x N) = A[z] B[z]^T on x3 panels; 1-D launch of cdiv(M,B) * cdiv(N,B) * batch workgroups in XCD-aware
 // order (N-tile fastest, then M-tile, then batch: an XCD's 32 CUs share one batch's panels in their L2).
 // Epilogues as in gemm.hip (apply / finish; SYMM epilogues also value / mirror and a run-time `symm` switch: then
@@ -247,8 +258,18 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
     for (int j = 0; j < Cfg::T; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  x3_mainloop<Cfg>(lds, K >> 5, oa, ob, acc);
   PipeAccMap<Cfg> map;
+  // Epilogues that read memory (read-modify-write outputs) may fetch their operands HERE, before the main loop: with one
+  // workgroup per CU nothing else hides those loads.  Pre = per-lane register image, one slot per accumulator element.
+  typename Epi::template Pre<Cfg::T> pre;
+#pragma unroll
+  for (int im = 0; im < Cfg::T; ++im)
+#pragma unroll
+    for (int in = 0; in < Cfg::T; ++in)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        epi.prefetch(pre, im, in, reg, m0 + map.row(im, reg), n0 + map.colof(in));
+  x3_mainloop<Cfg>(lds, K >> 5, oa, ob, acc);
   float local = 0.f;
 #pragma unroll
   for (int im = 0; im < Cfg::T; ++im)
@@ -256,11 +277,11 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
     for (int in = 0; in < Cfg::T; ++in)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
-        local += epi.apply(m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
+        local += epi.apply(pre, im, in, reg, m0 + map.row(im, reg), n0 + map.colof(in), acc[im][in][reg]);
   if constexpr (Epi::SYMM) {
     static_assert(!Epi::SYMM || Cfg::LDS_BYTES >= Cfg::BM * (Cfg::BN + 1) * 4, "mirror tile");
     // SYMM epilogues on this core store only the upper triangle themselves: diagonal tiles mirror too
-    if (epi.symm && n0 >= m0) mirror(epi, reinterpret_cast<float*>(lds), m0, n0, M, N, acc, map);
+    if (epi.symm && n0 >= m0) mirror(epi, pre, reinterpret_cast<float*>(lds), m0, n0, M, N, acc, map);
   }
   __syncthreads();
   epi.finish(reinterpret_cast<float*>(lds), local);

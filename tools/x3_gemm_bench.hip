@@ -12,7 +12,8 @@
 #ifndef SYMM_SKIP
 #define SYMM_SKIP 0
 #endif
-struct EpiStore {
+struct EpiStore : X3NoPrefetch<EpiStore> {
+  using X3NoPrefetch<EpiStore>::apply;
   static constexpr bool SYMM = SYMM_SKIP != 0;      // SYMM_SKIP: tiles below the diagonal return at once (timing experiment)
   static constexpr int symm = 1;
   __device__ __forceinline__ float value(int, int, float v) const { return v; }
@@ -54,9 +55,9 @@ int main(int argc, char** argv) {
 #endif
   using Cfg = X3Cfg<TILE>;
   struct NoMirror {
-    __device__ void operator()(const EpiStore&, float*, int, int, int, int, f32x16 (&)[Cfg::T][Cfg::T], const PipeAccMap<Cfg>&) const {}
+    template <class P> __device__ void operator()(const EpiStore&, P&, float*, int, int, int, int, f32x16 (&)[Cfg::T][Cfg::T], const PipeAccMap<Cfg>&) const {}
   };
-  EpiStore e{dC, N, M, N, (long long)M * N};
+  EpiStore e{{}, dC, N, M, N, (long long)M * N};
   const unsigned gt = (M + TILE - 1) / TILE;
   dim3 grid(SYMM_SKIP ? gt * (gt + 1) / 2 : (unsigned)(gt * ((N + TILE - 1) / TILE) * batch));
   auto run = [&]() {

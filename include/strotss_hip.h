@@ -21,6 +21,7 @@
 #ifndef STROTSS_HIP_H
 #define STROTSS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

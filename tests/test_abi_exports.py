@@ -24,6 +24,21 @@ def test_header_declares_the_hot_path():
         assert must in syms
 
 
+def test_header_is_self_contained_c99(tmp_path):
+    """The boundary is a C ABI: the header must compile on its own as plain C (what a cgo / JNI / ctypes-free
+    binding would include), with no C++ and no HIP types in the signatures."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "strotss_hip.h"\nint main(void) { return strotss_abi_version == 0; }\n')
+    out = subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.dirname(HEADER), str(src)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
 def test_library_exports_every_declared_symbol():
     from nn import _hip
     if not os.path.exists(_hip.LIB_PATH):

@@ -33,7 +33,7 @@ def test_header_is_self_contained_c99(tmp_path):
     if cc is None:
         pytest.skip("no C compiler")
     src = tmp_path / "use_header.c"
-    src.write_text('#include "strotss_hip.h"\nint main(void) { return strotss_abi_version == 0; }\n')
+    src.write_text('#include "strotss_hip.h"\nint (*probe)(void) = strotss_abi_version;\nint main(void) { return probe == 0 ? 1 : 0; }\n')
     out = subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.dirname(HEADER), str(src)],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr

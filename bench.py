@@ -170,6 +170,38 @@ def pairwise_roofline(dev, iters=50):
             "executed_bf16_tflops": round(6 * tf, 1) if x3 else None, "bf16_mfma_peak_tflops": 2500.0 if x3 else None}
 
 
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def hbm_families(fam, params, S):
+    """The HBM-bound families of a step against the HBM peak: ALGORITHMIC bytes (each tensor read / written once) over
+    the family's HIP-event time ('each family against its own bound')."""
+    pooled, ch, cw, first_out = 0.0, S, S, None
+    for it in params.cfg:
+        if it == 'pool':
+            ch, cw = ch // 2, cw // 2
+            pooled += ch * cw * prev_c
+        else:
+            prev_c = it[2]
+            if first_out is None:
+                first_out = S * S * it[2]
+    img = 3.0 * S * S
+    pyr = sum(3.0 * max(S >> k, 1) ** 2 for k in range(6))            # the 6 Laplacian variables
+    gb = {
+        "maxpool2_bwd": pooled * (4 + 1 + 16),                         # pooled gradient + argmax code in, 4 gradients out
+        "conv3x3_c3_fwd": 4.0 * (img + first_out),                     # image in, 64-channel map out
+        "conv3x3_c3_dgrad": 4.0 * (first_out + img),                   # 64-channel gradient in, pixel gradient out
+        "rmsprop_step": 4.0 * 5 * pyr,                                 # var, rms, grad in; var, rms out
+    }
+    out = {}
+    for name, nbytes in gb.items():
+        if name in fam and fam[name]["ms_per_step"] > 0:
+            rate = nbytes / (fam[name]["ms_per_step"] * 1e-3) / 1e9
+            out[name] = {"algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(rate, 1),
+                         "frac_of_hbm_peak": round(rate / HBM_PEAK_GBPS, 3)}
+    return out
+
+
 def pmc_traffic(path=os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.csv")):
     """HBM bytes per conv launch from the committed PMC passes (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
     in separate runs of this script, condensed by tools/summarize_rocprof.py with the gfx950 FETCH_SIZE x2
@@ -398,6 +430,7 @@ def main():
             if out["roofline_pairwise"].get("executed_bf16_tflops"):
                 out["roofline_pairwise"]["traffic"] = pmc_traffic_pairwise()
             out["kernel_families_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(fam.items())}
+            out["hbm_bound_families"] = hbm_families(fam, params, S)
     if rank == 0 and not args.no_pyramid and world == 1:
         del eng
         torch.cuda.empty_cache()

@@ -6,12 +6,12 @@
 //     x*y = hh + (hm + mh) + (hl + mm + lh) + [ml + lm + ll],
 // where each partial product is EXACT in f32 (8 x 8 bits) and the bracket is below 2^-24 relative.  The
 // six leading partial products on v_mfma_f32_32x32x16_bf16 with f32 accumulation give f32-class accuracy
-// (tests/test_hip_ops.py::test_x3_gemm_accuracy: error against fp64 not above the native f32-MFMA path)
+// (tests/test_hip_ops.py::test_x3_gemm_accuracy: error against fp64 at the native f32-MFMA path's level)
 // at 6/16 of the f32-MFMA cost.  This is NOT a reduced-precision mode: inputs, outputs and accumulators
 // are f32; the split is a change of number representation, not a rounding.
 //
-// Operand format ("x3 panels"): both operands arrive PRE-SPLIT from their producers (the Winograd input
-// transform, the weight pack, the feature-row pass), K-blocked so that what a workgroup stages per K-step
+// Operand format ("x3 panels"): both operands arrive PRE-SPLIT from their producers (the feature-row norm pass, the
+// centring / transposing pass, the epilogue of a preceding GEMM, the Winograd input transform and weight pack), K-blocked so that what a workgroup stages per K-step
 // is contiguous:
 //     element (kb, plane, row, k)  at  base + ((kb * 3 + plane) * rows + row) * 32 + k      (bf16)
 // with kb = K-block of 32, plane in {h, m, l} (an operand whose values are exact in bf16 may carry the h plane only:
@@ -66,7 +66,7 @@ __device__ __forceinline__ void x3_store4(__bf16* base, size_t rows, size_t row,
 // s+2 stays in flight ACROSS the barrier) + lgkmcnt(0) + raw s_barrier in the second k-chunk, then the first
 // fragments of tile s+1.  No staging registers, no ds_write, no VALU in the loop besides 4 address adds.
 // NPB_ = planes of the B operand: 3 (general f32 values) or 1 (values exact in bf16, e.g. a sign matrix: B = h, its
-// m and l planes would be zero -- three partial products instead of six, a quarter of the B bytes).
+// m and l planes would be zero -- three partial products instead of six, a third of the B bytes).
 template <int B_, int NPB_ = 3>
 struct X3Cfg {               // square block tile B x B, B = 128 (64 x 64 per wave) or 64 (32 x 32 per wave)
   static_assert(B_ == 128 || B_ == 64, "x3 main loop: 128 x 128 or 64 x 64 tiles");

@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
 // CUs; with fewer -- idle CUs, half-empty 128-row tiles -- the f32 core's smaller tiles win: 512-px scale 2.28 vs 2.41
 // ms/step).  Why not the default: the GEMMs themselves run 1.55x faster (512->512 @128x128 px: 172 -> 112 us, the layer
 // 209 -> 153 us), but the chip is power-limited in this workload and the denser bf16 MFMA work lowers the clock of every
-// OTHER kernel of the step by 3-4 % (tools/trunk_layer_times.py); measured net effect on the 1024-px step on three
-// MI355X boxes: +2.8 %, +-0 %, -1.5 %.  The cost matrices of the loss section use the same core by default.
+// OTHER kernel of the step by 3-4 % (tools/trunk_layer_times.py); measured net effect on the 1024-px step on four
+// MI355X boxes: +2.8 %, +-0 %, -1.5 %, -1.9 %.  The cost matrices of the loss section use the same core by default.
 static bool x3_enabled(size_t T, int cout) {
   static int on = -1;
   static long min_tiles = 1024;

@@ -440,14 +440,17 @@ def scale_schedule(level: int, start_level: int = 0):
 def run_scales(content: torch.Tensor, style: torch.Tensor, weights, *, level: int = 4,
                start_level: int = 0, max_iter: int = 200, lr: float = 2e-3,
                alpha: float = 1.0, seed: int = 0, sample_size: int = 1024,
-               dtype=torch.float32, index_stream=None, trace=None):
+               dtype=torch.float32, index_stream=None, trace=None, scale_trace=None, previous_override=None):
     """The coarse-to-fine driver of run_strotss.py:43-161 (no masks) on CPU tensors.
     `index_stream(scale_i, it, h, w)` may inject the (n,2) indices; by default they come
-    from make_indices with np.random.default_rng(seed).  Returns the float stylised image."""
+    from make_indices with np.random.default_rng(seed).  Returns the float stylised image.
+    `scale_trace` (a list) receives per executed scale dict(i, scl, lr, alpha, loss_denom, init, final);
+    `previous_override(i)` may return the image to take as the previous scale's result at scale i (tests
+    re-synchronise free-running trajectories with it), or None to keep the oracle's own."""
     rng = np.random.default_rng(seed)
     vgg = VGG(weights, dtype=dtype)
     content = content.to(dtype); style = style.to(dtype)
-    a = alpha * 16.0
+    a = alpha * 16.0 / 2.0 ** start_level      # alpha is halved after every scale of the schedule, skipped ones included
     stylized = None
     executed = list(range(start_level, level))
     for n_exec, i in enumerate(executed):
@@ -455,6 +458,10 @@ def run_scales(content: torch.Tensor, style: torch.Tensor, weights, *, level: in
         c = resize(content, scl); s = resize(style, scl)
         lap = make_laplacian(c)
         cur_lr = lr
+        if previous_override is not None and n_exec > 0:
+            over = previous_override(i)
+            if over is not None:
+                stylized = over.to(dtype)
         if n_exec == 0:
             stylized = lap + s.mean(dim=(1, 2), keepdim=True)
         elif i < level - 1:
@@ -465,6 +472,8 @@ def run_scales(content: torch.Tensor, style: torch.Tensor, weights, *, level: in
         variables = [v.clone().requires_grad_(True) for v in make_laplacian_pyramid(stylized)]
         rms = [torch.zeros_like(v) for v in variables]
         denom = 2.0 + a + 1.0 / max(a, 1.0)
+        if scale_trace is not None:
+            scale_trace.append(dict(i=i, scl=scl, lr=cur_lr, alpha=a, loss_denom=denom, init=stylized.clone()))
         with torch.no_grad():
             c_feat = [c] + vgg(c)
             s_feat = [s] + vgg(s)
@@ -482,5 +491,7 @@ def run_scales(content: torch.Tensor, style: torch.Tensor, weights, *, level: in
                 trace.append((i, it, float(res["loss"]), float(res["loss_c"]), float(res["loss_s"])))
         with torch.no_grad():
             stylized = fold_laplacian_pyramid([v.detach() for v in variables])
+        if scale_trace is not None:
+            scale_trace[-1]["final"] = stylized.clone()
         a /= 2.0
     return stylized

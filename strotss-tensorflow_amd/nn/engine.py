@@ -51,9 +51,10 @@ class StepEngine:
     """One scale of the coarse-to-fine loop: owns the 6 pyramid variables and their RMSprop slots.
 
     `regions` > 1 is the masked path (run_strotss.py:104-125): one trunk forward/backward, one
-    index set + loss group per region, loss = mean over regions.  With `dist_group`, regions are
-    dealt round-robin to the ranks and the pixel gradient is all-reduced (sum) before the fold
-    adjoint, so every rank applies the identical update."""
+    index set + loss group per region, loss = mean over regions.  With `dist_group` (a ProcessGroup, or
+    `parallel.WORLD` for torch.distributed's default group), regions are dealt round-robin to the ranks and the
+    pixel gradient is all-reduced (sum) before the fold adjoint, so every rank applies the identical update.
+    The logged scalars ride in the tail of the same buffer: ONE all-reduce per step."""
 
     N_SCALARS = 4   # loss_c, l_moment, l_remd, l_palette per region
 
@@ -83,6 +84,14 @@ class StepEngine:
         if strips is not None:
             assert self.R == 1 and strips.h == h, "image strips: one region, plan made for this scale"
         self.trunk = VGGTrunk(params, win1 - win0, w, with_grad=True)
+        # region sharding (masked runs): pixel gradient + the regions' scalars in ONE buffer = one all-reduce
+        self.group = dist_group
+        self.rank, self.world = parallel.world_info(dist_group) if dist_group is not None else (0, 1)
+        self.my_regions = parallel.regions_for_rank(self.R, self.rank, self.world)
+        self._reduce_buf = None
+        if self.world > 1 and strips is None:
+            self._reduce_buf = torch.zeros(3 * h * w + self.R * 8, dtype=torch.float32, device=dev)
+            self.trunk.gimg = self._reduce_buf[:3 * h * w].view(1, h, w, 3)
         self.d = 3 + sum(int(a.shape[-1]) for a in (self.trunk.acts[i] for i in self.trunk.taps))
         self.ld = _ops.pad32(self.d)
         rows = _ops.pad32(sample_size)
@@ -90,7 +99,8 @@ class StepEngine:
         self.cf = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
         self.pf = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
         self.gp = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
-        self.scalars = torch.zeros((self.R, 8), dtype=torch.float32, device=dev)
+        self.scalars = (torch.zeros((self.R, 8), dtype=torch.float32, device=dev) if self._reduce_buf is None
+                        else self._reduce_buf[3 * h * w:].view(self.R, 8))
         # gradient of the variables: level 0 aliases the pixel gradient
         if strips is not None:
             # full-size pixel gradient, zero outside the window; the trunk writes its window rows in place
@@ -118,15 +128,12 @@ class StepEngine:
         self._mt_content = _hip.make_maps(self.content_feat, self.divs)
         self._layer_to_map = {li: k + 1 for k, li in enumerate(self.trunk.taps)}
         self._layer_to_map[-1] = 0
-        # region sharding
-        self.group = dist_group
-        self.rank, self.world = parallel.world_info(dist_group) if dist_group is not None else (0, 1)
-        self.my_regions = parallel.regions_for_rank(self.R, self.rank, self.world)
         if strips is not None:            # strips shard the image, not the regions: every rank runs region 0
             self.my_regions, self.world = [0], 1
         self._idx: List[Optional[torch.Tensor]] = [None] * self.R
         self.steps_done = 0
         self._graph = None
+        self._graph_post = None           # sharded regions: the part of the step after the all-reduce
         self._graph_idx: List[torch.Tensor] = []
         self._graph_n: List[int] = []
 
@@ -179,6 +186,12 @@ class StepEngine:
             parallel.allreduce_sum_(self.gimg_full, self.group)   # windows overlap by the margins: sum
             self._fold_adjoint()
             return
+        self._pixel_gradient(indices)
+        self._reduce()
+        self._fold_adjoint()
+
+    def _pixel_gradient(self, indices: Sequence[torch.Tensor]) -> None:
+        """fold, trunk forward, this rank's regions' samples + losses, trunk data-gradient -> trunk.gimg, scalars"""
         if self.world > 1:
             self.scalars.zero_()          # regions owned by other ranks arrive through the all-reduce
         img = self.fold_forward()
@@ -192,13 +205,14 @@ class StepEngine:
             self._gather(self._mt_pred, idx, self.pf[r])
             self._losses(r, n)
         if self.my_regions:
-            gimg = self.trunk.backward(self._scatter)
+            self.trunk.backward(self._scatter)
         else:
-            gimg = self.trunk.gimg.zero_()
-        if self.world > 1:
-            parallel.allreduce_sum_(gimg, self.group)          # one RCCL all-reduce on the pixel gradient
-            parallel.allreduce_sum_(self.scalars, self.group)   # (tiny) so every rank can log
-        self._fold_adjoint()
+            self.trunk.gimg.zero_()
+
+    def _reduce(self) -> None:
+        """sharded regions: ONE all-reduce(sum) over [pixel gradient | scalars] (RCCL over xGMI; 12 MiB at 1024^2)"""
+        if self._reduce_buf is not None:
+            parallel.allreduce_sum_(self._reduce_buf, self.group)
 
     def _fold_adjoint(self) -> None:
         """gvars[k] = up^T(gvars[k-1]): adjoint of the fold"""
@@ -250,6 +264,9 @@ class StepEngine:
             for dst, src in zip(self._graph_idx, indices):
                 dst.copy_(src, non_blocking=True)
             self._graph.replay()
+            if self._graph_post is not None:       # sharded regions: graph | all-reduce | graph
+                self._reduce()
+                self._graph_post.replay()
         else:
             self.forward_backward(indices)
             self.apply_gradients()
@@ -260,26 +277,39 @@ class StepEngine:
         replay as one submission; the 64-256 px scales are otherwise bound by host launch rate).  Index
         sets are copied into static buffers before each replay; a step whose index counts differ from
         the captured ones runs eagerly.  The captured step does not advance the optimisation: the
-        variables / RMSprop slots are snapshotted around the warm-up and capture passes."""
-        if self.world > 1 or self.strips is not None:
-            return                      # collectives stay outside graphs in this build
+        variables / RMSprop slots are snapshotted around the warm-up and capture passes.
+        Sharded regions (world > 1): the all-reduce stays outside -- TWO graphs, [fold .. pixel gradient] and
+        [fold adjoint + RMSprop], with the collective launched between their replays.  Image strips run eagerly
+        (their per-step sample blocks change size)."""
+        if self.strips is not None:
+            return
         snap = [t.clone() for t in self.variables + self.rms]
         self._graph_idx = [i.clone() for i in example_indices]
         self._graph_n = [int(i.shape[0]) for i in example_indices]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):              # warm-up on the side stream (workspace allocation)
-            self.forward_backward(self._graph_idx)
+            self._pixel_gradient(self._graph_idx)
+            self._fold_adjoint()
             self.apply_gradients()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.forward_backward(self._graph_idx)
-            self.apply_gradients()
+        g, post = torch.cuda.CUDAGraph(), None
+        if self.world > 1:
+            with torch.cuda.graph(g):
+                self._pixel_gradient(self._graph_idx)
+            post = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(post):
+                self._fold_adjoint()
+                self.apply_gradients()
+        else:
+            with torch.cuda.graph(g):
+                self._pixel_gradient(self._graph_idx)
+                self._fold_adjoint()
+                self.apply_gradients()
         for t, s0 in zip(self.variables + self.rms, snap):
             t.copy_(s0)
-        self._graph = g
+        self._graph, self._graph_post = g, post
 
     # ------------------------------------------------------------------ read-outs (host sync)
     def losses(self) -> dict:

@@ -55,18 +55,28 @@ def synthetic_weights(vgg_type: str = '16', seed: int = 0) -> List[Tuple[torch.T
 
 def load_weights(path: str, vgg_type: str = '16') -> List[Tuple[torch.Tensor, torch.Tensor]]:
     """.npz with arrays `<layer>/kernel` (3,3,Cin,Cout HWIO, the Keras layout) and `<layer>/bias`,
-    or torchvision-style `features.<i>.weight` (Cout,Cin,3,3) / `.bias` in layer order."""
+    or a torchvision-style state dict saved as .npz: `features.<i>.weight` (Cout,Cin,3,3) / `features.<i>.bias` in
+    layer order (the batch-norm-free vgg16 / vgg19; `classifier.*` and any other keys are ignored).
+    Returns [(HWIO kernel, bias)] in Keras layer order (the reference fetches vgg16_norm.h5 instead, model.py:31-33)."""
     z = np.load(path)
-    names = [it[0] for it in vgg_config(vgg_type) if it != 'pool']
+    cfg = [it for it in vgg_config(vgg_type) if it != 'pool']
+    names = [it[0] for it in cfg]
     out = []
     if f'{names[0]}/kernel' in z:
         for n in names:
             out.append((torch.from_numpy(z[f'{n}/kernel']).float(), torch.from_numpy(z[f'{n}/bias']).float()))
-        return out
-    keys = sorted((k for k in z.files if k.endswith('.weight')), key=lambda k: int(k.split('.')[1]))
-    for k in keys[:len(names)]:
-        w = torch.from_numpy(z[k]).float().permute(2, 3, 1, 0).contiguous()   # OIHW -> HWIO
-        out.append((w, torch.from_numpy(z[k.replace('.weight', '.bias')]).float()))
+    else:
+        keys = sorted((k for k in z.files if k.startswith('features.') and k.endswith('.weight') and z[k].ndim == 4),
+                      key=lambda k: int(k.split('.')[1]))
+        if len(keys) != len(names):
+            raise ValueError(f"{path}: {len(keys)} convolution kernels `features.<i>.weight`, VGG{vgg_type} has {len(names)}")
+        for k in keys:
+            w = torch.from_numpy(z[k]).float().permute(2, 3, 1, 0).contiguous()   # OIHW -> HWIO
+            out.append((w, torch.from_numpy(z[k[:-len('.weight')] + '.bias']).float()))
+    for (name, cin, cout), (w, b) in zip(cfg, out):
+        if tuple(w.shape) != (3, 3, cin, cout) or tuple(b.shape) != (cout,):
+            raise ValueError(f"{path}: {name} has kernel {tuple(w.shape)} / bias {tuple(b.shape)}, expected "
+                             f"(3, 3, {cin}, {cout}) / ({cout},)")
     return out
 
 

@@ -33,11 +33,42 @@ import numpy as np
 import torch
 
 
+WORLD = "world"      # StepEngine(dist_group=WORLD): shard over torch.distributed's default process group
+
+
+def resolve_group(group):
+    """WORLD -> None (what torch.distributed takes for the default group); a ProcessGroup stays itself."""
+    return None if (isinstance(group, str) and group == WORLD) else group
+
+
 def world_info(group=None):
     import torch.distributed as dist
+    group = resolve_group(group)
     if group is None and not (dist.is_available() and dist.is_initialized()):
         return 0, 1
     return dist.get_rank(group), dist.get_world_size(group)
+
+
+def init_from_env(device_index=None):
+    """Join the process group torchrun describes (RANK / WORLD_SIZE / MASTER_*): backend "nccl" (= RCCL over xGMI)
+    unless STROTSS_DIST_BACKEND says otherwise (gloo: rehearsal of N ranks on one GPU or on the CPU).  Returns
+    (rank, world); (0, 1) without touching torch.distributed when WORLD_SIZE is absent or 1."""
+    import os
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("STROTSS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            if device_index is None:
+                device_index = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(device_index)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size()
 
 
 def regions_for_rank(n_regions: int, rank: int, world: int) -> List[int]:
@@ -48,6 +79,7 @@ def regions_for_rank(n_regions: int, rank: int, world: int) -> List[int]:
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum over the ranks (RCCL all-reduce over xGMI on GPU tensors; gloo on CPU)."""
     import torch.distributed as dist
+    group = resolve_group(group)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
@@ -70,7 +102,7 @@ def aggregate_throughput(units_per_rank: float, elapsed_local: float, group=None
     rank, world = world_info(group)
     t = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=resolve_group(group))
     elapsed = float(t.item())
     return world * units_per_rank / elapsed, elapsed
 

@@ -14,6 +14,9 @@ Every reference flag is kept (run_strotss.py:165-178 there).  Additions:
   --strips          under torchrun (one process per GPU): ONE image on all GPUs -- every rank runs the trunk on its strip
                     of the image (+ halo) at the scales where that pays, two all-reduces per step (nn/parallel.py);
                     rank 0 writes the output
+Under torchrun WITH masks (region-guided run, BASELINE config 4) the mask regions are dealt round-robin to the ranks:
+every rank runs the replicated trunk forward, its own regions' samples + losses and their data-gradient, ONE RCCL
+all-reduce sums the pixel gradient, every rank applies the identical update; rank 0 writes the output.
 `--level` is coerced to int (the reference declares type=float, which breaks `range(args.level)`).
 """
 import argparse
@@ -90,9 +93,9 @@ def _style_targets(params, style, style_masks, sampling):
     return targets
 
 
-def _optimise_scale(eng, scl: int, content_masks, args, dev, quiet: bool = False):
+def _optimise_scale(eng, scl: int, content_masks, args, dev, quiet: bool = False, step_trace=None):
     """`max_iter` RMSprop steps; fresh sample coordinates every step (they are drawn inside the reference's
-    traced train_step as well)."""
+    traced train_step as well).  `step_trace`: a list receiving every step's loss dict (one host sync per step)."""
     from nn import parallel
     masks_here = [None if m is None else strotss.mask_at_scale(m, eng.h, eng.w) for m in content_masks]
     log_every = max(1, int(getattr(args, "log_every", 10)))
@@ -126,13 +129,18 @@ def _optimise_scale(eng, scl: int, content_masks, args, dev, quiet: bool = False
             if it == 0 and not getattr(args, "no_graph", False):
                 eng.capture_graph(idx)
             eng.step(idx, offsets)
+            if step_trace is not None:
+                step_trace.append(eng.losses())
             if (it + 1) % log_every == 0 or it + 1 == args.max_iter:
                 r = eng.losses()
                 bar.set_description(f"Scale: {scl:4d} - It: {it+1:4d}")
                 bar.set_postfix({k: f'{r[k]:.3f}' for k in ('loss', 'loss_c', 'loss_s')})
 
 
-def run(args: argparse.Namespace):
+def run(args: argparse.Namespace, trace=None):
+    """The reference's run(args) (run_strotss.py:43-161).  `trace` (a list) receives one dict per executed scale:
+    scale index and size, lr, alpha, loss_denom, the image the scale starts from, every step's losses and the
+    result -- what the parity test of the schedule compares with the oracle's run_scales."""
     timer = utils.Timer()
     timer.start()
 
@@ -140,13 +148,10 @@ def run(args: argparse.Namespace):
     rand.seed_everything(seed)
     from nn import parallel
     rank, world = 0, 1
-    if getattr(args, "strips", False) and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
-            dist.init_process_group(os.environ.get("STROTSS_DIST_BACKEND", "nccl"))
-        rank, world = dist.get_rank(), dist.get_world_size()
+    masked = bool(getattr(args, "content_mask", None))
+    if (getattr(args, "strips", False) or masked) and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+        rank, world = parallel.init_from_env(torch.cuda.current_device())
     dev = utils.device()
     level, first = int(args.level), int(getattr(args, "start_level", 0))
 
@@ -164,13 +169,22 @@ def run(args: argparse.Namespace):
         scl_content, scl_style = utils.resize(content, scl), utils.resize(style, scl)
         stylized, lr = _initial_image(position, position > 0 and i == level - 1, stylized, scl_content, scl_style,
                                       args.lr)
-        plan = parallel.strip_plan(int(scl_content.shape[1]), world, rank) if world > 1 and style_masks == [None] else None
+        plan = (parallel.strip_plan(int(scl_content.shape[1]), world, rank)
+                if world > 1 and not masked and getattr(args, "strips", False) else None)
         eng = strotss_engine.StepEngine(
             vgg.params, strotss_engine.extract_features(vgg.params, scl_content),
             _style_targets(vgg.params, scl_style, style_masks, sampling), stylized, alpha,
-            loss_denom=2. + alpha + 1. / max(alpha, 1.), lr=lr, sample_size=SAMPLE_SIZE, strips=plan)
-        _optimise_scale(eng, scl, content_masks, args, dev, quiet=rank != 0)
+            loss_denom=2. + alpha + 1. / max(alpha, 1.), lr=lr, sample_size=SAMPLE_SIZE, strips=plan,
+            dist_group=parallel.WORLD if (world > 1 and masked) else None)
+        rec = None
+        if trace is not None:
+            rec = dict(i=i, scl=scl, lr=lr, alpha=alpha, loss_denom=eng.loss_denom, init=stylized.clone(), steps=[],
+                       hw=(eng.h, eng.w))
+            trace.append(rec)
+        _optimise_scale(eng, scl, content_masks, args, dev, quiet=rank != 0, step_trace=None if rec is None else rec["steps"])
         stylized = eng.stylized()
+        if rec is not None:
+            rec["final"] = stylized.clone()
         del eng
         alpha /= 2.
 

@@ -306,6 +306,58 @@ def test_cli_end_to_end(tmp_path):
         RS.run(bad)
 
 
+def _write_pair(tmp_path, seed=3):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    for name, (h, w) in (("c.jpg", (200, 256)), ("s.jpg", (180, 150))):
+        arr = (rng.random((h // 8, w // 8, 3)) * 255).astype(np.uint8)
+        Image.fromarray(arr).resize((w, h), Image.BILINEAR).save(tmp_path / name, quality=95)
+    return str(tmp_path / "c.jpg"), str(tmp_path / "s.jpg")
+
+
+@pytest.mark.parametrize("start_level", [0, 1])
+def test_run_schedule_matches_oracle_run_scales(tmp_path, start_level):
+    """the multi-scale driver run() against the oracle's run_scales (run_strotss.py:65-96,154-155 of
+    the reference) over 3 (2 with --start_level 1) scales x 2 steps at 64 -> 256 px with the same seed, i.e. the same
+    index stream (style draw per scale, then one draw per step).  Per scale: size, lr (halved on the last), alpha,
+    loss_denom, the initial image of each of the three branches (2e-6) and the first step's losses (5e-5).  The oracle
+    is re-synchronised to the product's result at every scale boundary: free-running trajectories differ by whole
+    RMSprop quanta wherever a near-zero gradient entry changes sign."""
+    import run_strotss as RS
+    from nn import utils
+    from nn.model import synthetic_weights
+    cpath, spath = _write_pair(tmp_path)
+    args = RS.build_parser().parse_args([cpath, spath, "-o", str(tmp_path / "o.jpg"), "--level", "3", "--max_iter", "2",
+                                         "--log_every", "1", "--start_level", str(start_level), "--seed", "5"])
+    tr = []
+    final = RS.run(args, trace=tr)
+    n_scales = 3 - start_level
+    assert len(tr) == n_scales and all(len(t["steps"]) == 2 for t in tr)
+    content = utils.load_image(cpath).cpu().double()
+    style = utils.load_image(spath).cpu().double()
+    finals = {t["i"]: t["final"].cpu().double() for t in tr}
+    otr, osteps = [], []
+    O.run_scales(content, style, synthetic_weights('16', 5), level=3, start_level=start_level, max_iter=2, lr=2e-3,
+                 alpha=1.0, seed=5, sample_size=1024, dtype=torch.float64, scale_trace=otr, trace=osteps,
+                 previous_override=lambda i: finals.get(i - 1))
+    assert len(otr) == n_scales
+    for t, o in zip(tr, otr):
+        assert (t["i"], t["scl"]) == (o["i"], o["scl"])
+        assert t["lr"] == o["lr"] and t["alpha"] == o["alpha"] and abs(t["loss_denom"] - o["loss_denom"]) < 1e-12
+        assert tuple(t["init"].shape) == tuple(o["init"].shape)
+        assert float((t["init"].cpu().double() - o["init"]).abs().max()) < 2e-6, t["i"]
+        first = [s_ for s_ in osteps if s_[0] == t["i"] and s_[1] == 0][0]
+        for k, ref in zip(("loss", "loss_c", "loss_s"), first[2:]):
+            assert abs(t["steps"][0][k] - ref) < 5e-5 * max(1.0, abs(ref)), (t["i"], k, t["steps"][0][k], ref)
+        second = [s_ for s_ in osteps if s_[0] == t["i"] and s_[1] == 1][0]
+        assert abs(t["steps"][1]["loss"] - second[2]) < 1e-2 * abs(second[2])
+        # fresh RMSprop slots per scale: after 2 steps no pixel moved by more than 2 first-step quanta per level
+        assert float((t["final"] - t["init"]).abs().max()) <= 6 * 2 * 10 * t["lr"] * 1.05
+    assert [t["lr"] for t in tr][-1] == 1e-3 and all(t["lr"] == 2e-3 for t in tr[:-1])
+    assert [t["alpha"] for t in tr] == [16.0 / 2 ** i for i in range(start_level, 3)]
+    assert final.dtype == torch.uint8 and tuple(final.shape) == (200, 256, 3)
+
+
 def test_cli_with_masks(tmp_path):
     """Region-guided run (run_strotss.py:52-59, 97-125): load_mask pairs the colour regions, every
     region draws its own samples, one trunk pass serves all regions."""

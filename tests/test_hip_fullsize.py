@@ -191,17 +191,38 @@ def test_rmsprop_and_postprocess_properties_1024():
     assert int((again.int() - u8.int()).abs().max()) <= 1
 
 
-def test_engine_step_invariants_1024():
-    """One full step at the bench configuration: finite losses, the level-k gradient is the bilinear
-    adjoint of the level-(k-1) gradient, the update moves every variable by at most 10*lr."""
+@pytest.mark.parametrize("scale,regions", [(1024, 1), (512, 1), (1024, 4)])
+def test_engine_step_invariants_fullsize(scale, regions):
+    """One full step at the bench configurations -- BASELINE config 3 (1024 px), config 2's last scale (512 px) and
+    config 4's masked step (1024 px, 4 mask regions: one trunk pass, four loss groups): finite losses, the level-k
+    gradient is the bilinear adjoint of the level-(k-1) gradient, the update moves every variable by at most 10*lr,
+    and the pixel gradient is the directional derivative of the logged loss (central difference along a random
+    direction of the finest variable: checks fold + trunk + gather + losses + their backward as a whole)."""
     import bench
     from nn import _ops
     from nn.model import VGGParams, synthetic_weights
     params = VGGParams(synthetic_weights('16', 0), '16', None, DEV)
-    eng, rng = bench.build_engine(params, S, torch.device(DEV), seed=0)
-    idx = bench.index_stream(S, 2, rng, torch.device(DEV))
+    eng, rng = bench.build_engine(params, scale, torch.device(DEV), seed=0, regions=regions)
+    assert eng.R == regions
+    idx = bench.index_stream(scale, 2, rng, torch.device(DEV), regions=regions)
     before = [t.clone() for t in eng.variables]
-    eng.step([idx[0]])
+    # directional derivative first (forward_backward does not move the variables)
+    eng.forward_backward(list(idx[0]))
+    g0 = eng.gvars[0].clone()
+    # along the gradient itself (scaled to unit max): a random direction's derivative drowns in the f32 rounding of the
+    # logged loss at this size
+    dirn = g0 / g0.abs().max()
+    want = _dot(g0, dirn)
+    eps = 2e-3
+    vals = []
+    for sgn in (1.0, -1.0):
+        eng.variables[0].copy_(before[0] + sgn * eps * dirn)
+        eng.forward_backward(list(idx[0]))
+        vals.append(eng.losses()["loss"])
+    eng.variables[0].copy_(before[0])
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert want > 0 and abs(fd - want) < 0.1 * want, (fd, want)       # L1 / hard-min terms are piecewise smooth
+    eng.step(list(idx[0]))
     torch.cuda.synchronize()
     ls = eng.losses()
     assert all(np.isfinite(v) and v >= 0 for v in ls.values()), ls
@@ -211,6 +232,36 @@ def test_engine_step_invariants_1024():
         assert torch.equal(ref, eng.gvars[k])
     for a, b in zip(eng.variables, before):
         assert float((a - b).abs().max()) <= 10 * eng.lr * 1.0001
+
+
+def test_pyramid_config2_runs_all_four_scales():
+    """BASELINE config 2: a 512-px pair through the full 4-scale pyramid (64 -> 512) of the CLI driver, with the
+    reference's default 200 steps per scale; checks the per-scale sizes and alpha schedule, that every scale lowers
+    its loss, and the output."""
+    import os, tempfile
+    import run_strotss as RS
+    from nn import utils
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = []
+        for name, seed in (("c.jpg", 100), ("s.jpg", 200)):
+            paths.append(os.path.join(tmp, name))
+            utils.write_image(bench_image(512, seed) * 255.0, paths[-1])
+        args = RS.build_parser().parse_args(paths + ["-o", os.path.join(tmp, "o.jpg"), "--max_size", "512", "--level", "4",
+                                                     "--max_iter", "200", "--log_every", "200"])
+        tr = []
+        final = RS.run(args, trace=tr)
+    assert [t["scl"] for t in tr] == [64, 128, 256, 512] and [t["hw"] for t in tr] == [(64, 64), (128, 128), (256, 256), (512, 512)]
+    assert [t["alpha"] for t in tr] == [16.0, 8.0, 4.0, 2.0] and [t["lr"] for t in tr] == [2e-3, 2e-3, 2e-3, 1e-3]
+    for t in tr:
+        assert len(t["steps"]) == 200
+        head = np.mean([s_["loss"] for s_ in t["steps"][:5]]); tail = np.mean([s_["loss"] for s_ in t["steps"][-20:]])
+        assert np.isfinite(tail) and tail < head, (t["scl"], head, tail)
+    assert tuple(final.shape) == (512, 512, 3) and final.dtype == torch.uint8
+
+
+def bench_image(size, seed):
+    import bench
+    return bench.synth_image(size, size, seed)
 
 
 def test_sinkhorn_fullsize_permutation_invariance_and_bounds():

@@ -321,6 +321,91 @@ def test_losses_fwd_bwd(ops, n, ns, d):
     run(lambda gp, lo: ops.moment_fwd_bwd(mean, cov, by, n, d, 3.0, gp, lo), l, g, 3.0, 3e-3, l1=True)
 
 
+def _tie_problem(ns, n, d, dup_style, dup_pred, seed):
+    """Features with exact duplicate rows (flat image regions give identical hypercolumns: ties are the normal
+    case on real images).  dup_*: lists of index groups made identical."""
+    x = _feat(ns, d, seed); y = _feat(n, d, seed + 1)
+    for grp in dup_style:
+        x[grp[1:]] = x[grp[0]]
+    for grp in dup_pred:
+        y[grp[1:]] = y[grp[0]]
+    return x, y
+
+
+@pytest.mark.parametrize("case", ["col_branch_dup_style", "row_branch_dup_pred", "both_dups_row", "both_dups_col"])
+def test_remd_and_palette_ties_split_like_tf_reduce_min(ops, case):
+    """losses.py:69-80 with TIED minima on the HIP kernels (rcnt / ccnt > 1 in remd_cos_bwd_kernel / palette_bwd_kernel):
+    tf.reduce_min's gradient is split equally among the ties.  Duplicate style rows tie inside a column (the R_Y
+    branch), duplicate prediction rows tie inside a row (the R_X branch); the branch is forced by the shape (many
+    predictions per style row -> R_Y > R_X and vice versa) and asserted on the float64 oracle."""
+    d = 67
+    if case == "col_branch_dup_style":
+        ns, n, ds, dp = 24, 200, [[1, 5, 9], [3, 20]], []
+    elif case == "row_branch_dup_pred":
+        ns, n, ds, dp = 200, 24, [], [[0, 7, 8, 21], [2, 3]]
+    elif case == "both_dups_row":
+        ns, n, ds, dp = 160, 40, [[4, 100], [9, 10, 11]], [[1, 2], [5, 30, 31]]
+    else:
+        ns, n, ds, dp = 40, 160, [[1, 2], [5, 30, 31]], [[4, 100], [9, 10, 11]]
+    x, y = _tie_problem(ns, n, d, ds, dp, 11)
+    want_row = case in ("row_branch_dup_pred", "both_dups_row")
+    for name in ("cos", "palette"):
+        if name == "cos":
+            C = R.cosine_distance(x, y)
+            l, g = R.relaxed_emd_cos_fwd_bwd(x, y)
+        else:
+            xy, yy = x[:, :3] @ R.RGB2YUV, y[:, :3] @ R.RGB2YUV
+            C = R.cosine_distance(xy, yy) + R.l2_distance(xy, yy)
+            l, g = R.palette_remd_fwd_bwd(x[:, :3], y[:, :3])
+        assert (C.min(1).mean() >= C.min(0).mean()) == want_row, "the case must take the intended branch"
+        # the ties are really there on the branch that carries the gradient
+        E = (C == C.min(1, keepdims=True)) if want_row else (C == C.min(0, keepdims=True))
+        assert (E.sum(1 if want_row else 0) > 1).any()
+        bx, by = _fbuf(ops, x), _fbuf(ops, y)
+        gp = torch.zeros_like(by); loss = torch.zeros(8, device="cuda")
+        if name == "cos":
+            ops.remd_cos_fwd_bwd(bx, ops.row_inv_norm(bx, ns), ns, by, n, d, 1.0, gp, loss)
+            got = gp[:n, :d].cpu().numpy()
+        else:
+            ops.palette_remd_fwd_bwd(bx, ns, by, n, 1.0, gp, loss)
+            got = gp[:n, :3].cpu().numpy()
+        torch.cuda.synchronize()
+        assert abs(float(loss[0]) - l) < 2e-5 * max(1.0, abs(l)), (name, float(loss[0]), l)
+        assert np.abs(got - g).max() / np.abs(g).max() < 1e-4, (name, np.abs(got - g).max() / np.abs(g).max())
+        # duplicated prediction rows receive bitwise identical gradients
+        for grp in dp:
+            for k in grp[1:]:
+                assert np.array_equal(got[k], got[grp[0]])
+
+
+def test_remd_exact_rx_equals_ry_takes_the_row_branch(ops):
+    """tf.maximum(R_X, R_Y) sends the gradient to R_X on an exact tie (losses.py:80).  A problem where R_X == R_Y
+    bitwise (every minimum is exactly 0.5: unit rows against rows of four equal components) but the two branches
+    weigh the entries differently: row 0 ties over three columns (1/(2*3) each), row 1 has one (1/2); the column
+    branch would give 1/4 everywhere."""
+    d = 35
+    x = np.zeros((2, d)); x[0, 0] = 1.0; x[1, 4] = 1.0
+    y = np.zeros((4, d)); y[:3, 0:4] = 1.0; y[3, 4:8] = 1.0
+    C = R.cosine_distance(x, y)
+    assert C.min(1).mean() == C.min(0).mean() == 0.5
+    l, g = R.relaxed_emd_cos_fwd_bwd(x, y)
+    yt = torch.from_numpy(y).clone().requires_grad_(True)
+    lo = O.relaxed_emd(torch.from_numpy(x), yt)
+    go, = torch.autograd.grad(lo, yt)
+    assert np.abs(g - go.numpy()).max() < 1e-15                      # both oracles: the row branch
+    # the column branch would differ: make sure the case can tell them apart
+    Wc = (C == C.min(0, keepdims=True)) / 4.0
+    Wr = (C == C.min(1, keepdims=True)); Wr = Wr / Wr.sum(1, keepdims=True) / 2.0
+    assert np.abs(Wc - Wr).max() > 0.08
+    bx, by = _fbuf(ops, x), _fbuf(ops, y)
+    gp = torch.zeros_like(by); loss = torch.zeros(8, device="cuda")
+    ops.remd_cos_fwd_bwd(bx, ops.row_inv_norm(bx, 2), 2, by, 4, d, 1.0, gp, loss)
+    torch.cuda.synchronize()
+    assert float(loss[0]) == 0.5
+    got = gp[:4, :d].cpu().numpy()
+    assert np.abs(got - g).max() < 1e-6 * np.abs(g).max(), np.abs(got - g).max()
+
+
 def test_loss_gradients_accumulate(ops):
     n, ns, d = 64, 64, 67
     x = _feat(ns, d, 6); y = _feat(n, d, 7); c = _feat(n, d, 8)

@@ -146,14 +146,41 @@ def test_postprocess():
     assert out.reshape(-1).tolist() == [0, 51, 102, 204, 255, 153]
 
 
-def test_loss_denominator_and_alpha_schedule():
-    a = 16.0
-    seen = []
-    for _ in range(5):
-        seen.append((a, 2.0 + a + 1.0 / max(a, 1.0)))
-        a /= 2
-    assert [s[0] for s in seen] == [16, 8, 4, 2, 1]
-    assert math.isclose(seen[0][1], 18.0625) and math.isclose(seen[-1][1], 4.0)
+def test_run_scales_schedule_init_lr_alpha():
+    """The oracle's coarse-to-fine driver against run_strotss.py:65-96,154-155 read as text: alpha 16, 8, 4 ...,
+    loss_denom = 2 + alpha + 1/max(alpha, 1) (92), the three initialisation branches (82 / 84-85 / 87-88: the last
+    scale gets lr/2 and NO Laplacian), fresh RMSprop slots per scale, `--start_level`."""
+    w = O.make_synthetic_vgg16_weights(0)
+    c = _img(40, 64, seed=1).float(); s = _img(48, 48, seed=2).float()
+    tr, steps = [], []
+    out = O.run_scales(c, s, w, level=3, max_iter=1, lr=2e-3, sample_size=64, scale_trace=tr, trace=steps)
+    assert [t["scl"] for t in tr] == [64, 128, 256] and [t["alpha"] for t in tr] == [16.0, 8.0, 4.0]
+    assert [t["lr"] for t in tr] == [2e-3, 2e-3, 1e-3]
+    for t in tr:
+        assert math.isclose(t["loss_denom"], 2.0 + t["alpha"] + 1.0 / max(t["alpha"], 1.0))
+    assert math.isclose(tr[0]["loss_denom"], 18.0625)
+    # sizes: long side = scl, int(h / factor)   (utils.py:32-37)
+    assert [tuple(t["init"].shape[1:3]) for t in tr] == [(40, 64), (80, 128), (160, 256)]
+    c0, s0 = O.resize(c, 64), O.resize(s, 64)
+    assert torch.equal(tr[0]["init"], O.make_laplacian(c0) + s0.mean(dim=(1, 2), keepdim=True))
+    c1 = O.resize(c, 128)
+    assert torch.equal(tr[1]["init"], O.resize_like(tr[0]["final"], c1) + O.make_laplacian(c1))
+    c2 = O.resize(c, 256)
+    assert torch.equal(tr[2]["init"], O.resize_like(tr[1]["final"], c2))
+    assert torch.equal(out, tr[2]["final"]) and len(steps) == 3
+    # one RMSprop step from zero slots moves every pixel by <= 10 * lr per level (6 levels)
+    assert float((tr[0]["final"] - tr[0]["init"]).abs().max()) <= 6 * 10 * 2e-3 * 1.01
+    # a single executed scale keeps the full lr (level = 1 in the reference never reaches the lr/2 branch)
+    tr1 = []
+    O.run_scales(c, s, w, level=1, max_iter=0, sample_size=64, scale_trace=tr1)
+    assert [t["lr"] for t in tr1] == [2e-3] and tr1[0]["alpha"] == 16.0
+    # --start_level 1: first executed scale initialised like the reference's first one
+    tr2 = []
+    O.run_scales(c, s, w, level=3, start_level=1, max_iter=0, sample_size=64, scale_trace=tr2)
+    assert [t["scl"] for t in tr2] == [128, 256] and [t["lr"] for t in tr2] == [2e-3, 1e-3]
+    assert [t["alpha"] for t in tr2] == [8.0, 4.0]            # alpha as the full schedule would have it at these scales
+    s1 = O.resize(s, 128)
+    assert torch.equal(tr2[0]["init"], O.make_laplacian(c1) + s1.mean(dim=(1, 2), keepdim=True))
 
 
 def test_train_step_runs_and_fold_adjoint():

@@ -112,6 +112,28 @@ def test_remd_tie_rules():
     assert np.abs(g - go).max() < 1e-15
 
 
+def test_remd_exact_tie_between_branches_is_asymmetric():
+    """R_X == R_Y exactly, yet the two branches weigh the entries differently (row 0 ties over three columns): the
+    gradient must be the ROW branch's (tf.maximum -> first argument), in both restatements."""
+    d = 8
+    x = np.zeros((2, d)); x[0, 0] = 1.0; x[1, 4] = 1.0
+    y = np.zeros((4, d)); y[:3, 0:4] = 1.0; y[3, 4:8] = 1.0
+    C = R.cosine_distance(x, y)
+    assert C.min(1).mean() == C.min(0).mean() == 0.5
+    l, g = R.relaxed_emd_cos_fwd_bwd(x, y)
+    lo, go = _autograd(lambda t: O.relaxed_emd(torch.from_numpy(x), t), y)
+    assert l == lo == 0.5 and np.abs(g - go).max() < 1e-15
+    # hand-computed row-branch weights: W = [[1/6,1/6,1/6,0],[0,0,0,1/2]]; dL/dyhat_j = -sum_i W_ij xhat_i
+    W = np.array([[1 / 6, 1 / 6, 1 / 6, 0], [0, 0, 0, 1 / 2]])
+    ghat = -(W.T @ x)
+    ry = R.inv_norm(y)
+    yh = y * ry[:, None]
+    want = ry[:, None] * (ghat - yh * (yh * ghat).sum(1, keepdims=True))
+    assert np.abs(g - want).max() < 1e-15
+    Wc = (C == C.min(0, keepdims=True)) / 4.0                       # the column branch would give this instead
+    assert np.abs(W - Wc).max() > 0.08
+
+
 def test_rmsprop_first_step():
     v = torch.zeros(5, dtype=torch.float64); r = torch.zeros(5, dtype=torch.float64)
     g = torch.tensor([1.0, -2.0, 0.5, 1e-3, -7.0], dtype=torch.float64)

@@ -116,3 +116,32 @@ def test_strip_plan_and_sample_ownership():
         rows = s[offs[r]:offs[r + 1], 0]
         assert ((rows >= plan.bounds[r]) & (rows < plan.bounds[r + 1])).all()
     assert sorted(map(tuple, s.tolist())) == sorted(map(tuple, idx.tolist()))
+
+
+def _bench(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, lines
+
+
+def test_bench_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it starts two ranks itself (child process, gloo rehearsal:
+    sleeping stand-in step, no GPU) and rank 0 prints ONE line with n_gpus = 2 and value = all ranks' steps / the MAX
+    over ranks of the time (rank 1 sleeps 20 ms per step, rank 0 10 ms)."""
+    out, lines = _bench(["--gpus", "2", "--rehearse", "--steps", "10", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 10
+    assert 20.0 <= lines[0]["ms_per_step"] < 40.0                  # the slow rank's pace
+    assert abs(lines[0]["value"] - 2 * 1e3 / lines[0]["ms_per_step"]) < 0.05 * lines[0]["value"]
+    one, l1 = _bench(["--rehearse", "--steps", "5", "--warmup", "0"])
+    assert one.returncode == 0 and l1[0]["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    out, lines = _bench(["--gpus", "4", "--rehearse"], env_extra={"WORLD_SIZE": "1", "RANK": "0"}, drop=())
+    assert out.returncode != 0 and not lines and "--gpus 4 but WORLD_SIZE=1" in out.stderr

@@ -32,8 +32,8 @@ def main():
         eng, rng = bench.build_engine(params, S, dev, seed=0, strips=plan)
         if plan is None:
             idx = bench.index_stream(S, 16, rng, dev)
-            step = lambda i: eng.step([idx[i % 16]])
-            eng.capture_graph([idx[0]])
+            step = lambda i: eng.step(list(idx[i % 16]))
+            eng.capture_graph(list(idx[0]))
         else:
             idx, offs = bench.strip_index_stream(S, 16, rng, dev, plan)
             step = lambda i: eng.step([idx[i % 16]], offs[i % 16])

@@ -20,7 +20,7 @@ def main():
     params = model.VGGParams(model.synthetic_weights('16', 0), '16', None, dev)
     eng, rng = bench.build_engine(params, scale, dev, 0)
     idx = bench.index_stream(scale, 16, rng, dev)
-    eng.capture_graph([idx[0]])
+    eng.capture_graph(list(idx[0]))
     bench.run_steps(eng, idx, 0, 5)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -19,57 +19,103 @@ __device__ __forceinline__ AxisTap axis_tap(int i, float scale, int in_size) {
   return t;
 }
 
+// One thread per OUTPUT PIXEL (all C channels), one workgroup row per output row: no 64-bit div/mod per element, the
+// two axis taps are computed once per pixel, the row bases once per row.  C = 0: channel count at run time.
+template <int C>
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, int ih, int iw,
-                                                              int c, float* __restrict__ out, int oh, int ow,
+                                                              int c_rt, float* __restrict__ out, int oh, int ow,
                                                               float sy, float sx, float alpha,
                                                               const float* __restrict__ add) {
-  const size_t total = (size_t)oh * ow * c;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int ch = (int)(e % c);
-    const size_t pix = e / c;
-    const int ox = (int)(pix % ow), oy = (int)(pix / ow);
-    const AxisTap ty = axis_tap(oy, sy, ih), tx = axis_tap(ox, sx, iw);
-    const float tl = in[((size_t)ty.lo * iw + tx.lo) * c + ch];
-    const float tr = in[((size_t)ty.lo * iw + tx.hi) * c + ch];
-    const float bl = in[((size_t)ty.hi * iw + tx.lo) * c + ch];
-    const float br = in[((size_t)ty.hi * iw + tx.hi) * c + ch];
-    const float top = tl + (tr - tl) * tx.lerp;
-    const float bot = bl + (br - bl) * tx.lerp;
-    float v = alpha * (top + (bot - top) * ty.lerp);
-    if (add) v += add[e];
-    out[e] = v;
+  const int c = C ? C : c_rt;
+  for (int oy = blockIdx.y; oy < oh; oy += gridDim.y) {
+    const AxisTap ty = axis_tap(oy, sy, ih);
+    const float* r0 = in + (size_t)ty.lo * iw * c;
+    const float* r1 = in + (size_t)ty.hi * iw * c;
+    const size_t orow = (size_t)oy * ow * c;
+    for (int ox = blockIdx.x * 256 + threadIdx.x; ox < ow; ox += gridDim.x * 256) {
+      const AxisTap tx = axis_tap(ox, sx, iw);
+      const int a = tx.lo * c, b = tx.hi * c;
+      const size_t o = orow + (size_t)ox * c;
+#pragma unroll
+      for (int ch = 0; ch < (C ? C : 1); ++ch)
+        for (int cc = ch; cc < c; cc += (C ? C : 1)) {
+          const float tl = r0[a + cc], tr = r0[b + cc], bl = r1[a + cc], br = r1[b + cc];
+          const float top = tl + (tr - tl) * tx.lerp;
+          const float bot = bl + (br - bl) * tx.lerp;
+          float v = alpha * (top + (bot - top) * ty.lerp);
+          if (add) v += add[o + cc];
+          out[o + cc] = v;
+        }
+    }
   }
 }
 
-// Adjoint as a gather: gin[iy,ix] = sum over the output pixels whose taps touch (iy,ix).
+// Adjoint as a gather: gin[iy,ix] = sum over the output pixels whose taps touch (iy,ix).  One thread per INPUT pixel
+// (all C channels); the candidate output rows / columns and their weights are found once per pixel (at most ADJ_MAX
+// per axis in registers: 2x upsampling has <= 6; wider ranges take the generic loop).  Summation order: output rows
+// ascending, columns ascending inside a row -- fixed, so the result is bitwise reproducible.
+#define ADJ_MAX 8
+__device__ __forceinline__ float adj_weight(int o, float scale, int in_size, int i) {
+  const AxisTap t = axis_tap(o, scale, in_size);
+  return (t.lo == i ? 1.0f - t.lerp : 0.f) + (t.hi == i ? t.lerp : 0.f);
+}
+template <int C>
 __global__ __launch_bounds__(256) void resize_adjoint_kernel(const float* __restrict__ gout, int oh, int ow,
-                                                             int c, float* __restrict__ gin, int ih, int iw,
+                                                             int c_rt, float* __restrict__ gin, int ih, int iw,
                                                              float sy, float sx) {
-  const size_t total = (size_t)ih * iw * c;
+  const int c = C ? C : c_rt;
   const float isy = 1.0f / sy, isx = 1.0f / sx;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int ch = (int)(e % c);
-    const size_t pix = e / c;
-    const int ix = (int)(pix % iw), iy = (int)(pix / iw);
+  for (int iy = blockIdx.y; iy < ih; iy += gridDim.y) {
     // candidates: src(o) in (i-1, i+1)  <=>  o in ((i-0.5)/s - 0.5, (i+1.5)/s - 0.5); +-1 safety margin
     const int oy0 = max(0, (int)floorf(((float)iy - 0.5f) * isy - 0.5f) - 1);
     const int oy1 = min(oh - 1, (int)ceilf(((float)iy + 1.5f) * isy - 0.5f) + 1);
-    const int ox0 = max(0, (int)floorf(((float)ix - 0.5f) * isx - 0.5f) - 1);
-    const int ox1 = min(ow - 1, (int)ceilf(((float)ix + 1.5f) * isx - 0.5f) + 1);
-    float acc = 0.f;
-    for (int oy = oy0; oy <= oy1; ++oy) {
-      const AxisTap ty = axis_tap(oy, sy, ih);
-      const float wy = (ty.lo == iy ? 1.0f - ty.lerp : 0.f) + (ty.hi == iy ? ty.lerp : 0.f);
-      if (wy == 0.f) continue;
-      float row = 0.f;
-      for (int ox = ox0; ox <= ox1; ++ox) {
-        const AxisTap tx = axis_tap(ox, sx, iw);
-        const float wx = (tx.lo == ix ? 1.0f - tx.lerp : 0.f) + (tx.hi == ix ? tx.lerp : 0.f);
-        if (wx != 0.f) row += wx * gout[((size_t)oy * ow + ox) * c + ch];
+    for (int ix = blockIdx.x * 256 + threadIdx.x; ix < iw; ix += gridDim.x * 256) {
+      const int ox0 = max(0, (int)floorf(((float)ix - 0.5f) * isx - 0.5f) - 1);
+      const int ox1 = min(ow - 1, (int)ceilf(((float)ix + 1.5f) * isx - 0.5f) + 1);
+      float acc[C ? C : 4];
+#pragma unroll
+      for (int ch = 0; ch < (C ? C : 4); ++ch) acc[ch] = 0.f;
+      if (C && ox1 - ox0 < ADJ_MAX) {
+        float wx[ADJ_MAX];
+#pragma unroll
+        for (int q = 0; q < ADJ_MAX; ++q) wx[q] = (ox0 + q <= ox1) ? adj_weight(ox0 + q, sx, iw, ix) : 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+          const float wy = adj_weight(oy, sy, ih, iy);
+          if (wy == 0.f) continue;
+          const float* g = gout + ((size_t)oy * ow + ox0) * c;
+          float row[C ? C : 1];
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch) row[ch] = 0.f;
+#pragma unroll
+          for (int q = 0; q < ADJ_MAX; ++q)
+            if (wx[q] != 0.f) {
+#pragma unroll
+              for (int ch = 0; ch < C; ++ch) row[ch] += wx[q] * g[q * c + ch];
+            }
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch) acc[ch] += wy * row[ch];
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) gin[((size_t)iy * iw + ix) * c + ch] = acc[ch];
+      } else {
+        for (int ch0 = 0; ch0 < c; ch0 += 4) {            // generic: any channel count, any range
+          const int nc = min(4, c - ch0);
+          float a4[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int oy = oy0; oy <= oy1; ++oy) {
+            const float wy = adj_weight(oy, sy, ih, iy);
+            if (wy == 0.f) continue;
+            float row[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int ox = ox0; ox <= ox1; ++ox) {
+              const float w = adj_weight(ox, sx, iw, ix);
+              if (w != 0.f)
+                for (int ch = 0; ch < nc; ++ch) row[ch] += w * gout[((size_t)oy * ow + ox) * c + ch0 + ch];
+            }
+            for (int ch = 0; ch < nc; ++ch) a4[ch] += wy * row[ch];
+          }
+          for (int ch = 0; ch < nc; ++ch) gin[((size_t)iy * iw + ix) * c + ch0 + ch] = a4[ch];
+        }
       }
-      acc += wy * row;
     }
-    gin[e] = acc;
   }
 }
 
@@ -237,9 +283,16 @@ int strotss_resize_bilinear(const float* in, int ih, int iw, int c, float* out, 
                             const float* add, void* stream) {
   ST_CHECK_ARG(in && out && ih > 0 && iw > 0 && oh > 0 && ow > 0 && c > 0, STROTSS_EINVAL);
   const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;   // CalculateResizeScale
-  const size_t total = (size_t)oh * ow * c;
-  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, in, ih, iw, c, out, oh, ow, sy, sx, alpha, add);
+  const dim3 grid((unsigned)cdiv(ow, 256), (unsigned)min(oh, 32768));
+  if (c == 3)
+    hipLaunchKernelGGL(resize_bilinear_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, in, ih, iw, c, out, oh, ow, sy, sx,
+                       alpha, add);
+  else if (c == 1)
+    hipLaunchKernelGGL(resize_bilinear_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, in, ih, iw, c, out, oh, ow, sy, sx,
+                       alpha, add);
+  else
+    hipLaunchKernelGGL(resize_bilinear_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, in, ih, iw, c, out, oh, ow, sy, sx,
+                       alpha, add);
   ST_LAUNCH_RET();
 }
 
@@ -247,9 +300,13 @@ int strotss_resize_bilinear_adjoint(const float* gout, int oh, int ow, int c, fl
                                     void* stream) {
   ST_CHECK_ARG(gout && gin && ih > 0 && iw > 0 && oh > 0 && ow > 0 && c > 0, STROTSS_EINVAL);
   const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
-  const size_t total = (size_t)ih * iw * c;
-  hipLaunchKernelGGL(resize_adjoint_kernel, dim3(min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, gout, oh, ow, c, gin, ih, iw, sy, sx);
+  const dim3 grid((unsigned)cdiv(iw, 256), (unsigned)min(ih, 32768));
+  if (c == 3)
+    hipLaunchKernelGGL(resize_adjoint_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, gout, oh, ow, c, gin, ih, iw, sy, sx);
+  else if (c == 1)
+    hipLaunchKernelGGL(resize_adjoint_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, gout, oh, ow, c, gin, ih, iw, sy, sx);
+  else
+    hipLaunchKernelGGL(resize_adjoint_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, gout, oh, ow, c, gin, ih, iw, sy, sx);
   ST_LAUNCH_RET();
 }
 

@@ -268,18 +268,18 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
   }
 }
 
-// OPT-IN (STROTSS_X3_CONV=1, default 0): the 36 GEMMs on the bf16x3 core (mfma_x3.h) where the weights' x3 panels are
-// given and the launch has at least STROTSS_X3_MIN_TILES 128 x 128 output tiles (default 1024 = four rounds of the 256
-// CUs; with fewer -- idle CUs, half-empty 128-row tiles -- the f32 core's smaller tiles win: 512-px scale 2.28 vs 2.41
-// ms/step).  Why not the default: the GEMMs themselves run 1.55x faster (512->512 @128x128 px: 172 -> 112 us, the layer
-// 209 -> 153 us), but the chip is power-limited in this workload and the denser bf16 MFMA work lowers the clock of every
-// OTHER kernel of the step by 3-4 % (tools/trunk_layer_times.py); measured net effect on the 1024-px step on four
-// MI355X boxes: +2.8 %, +-0 %, -1.5 %, -1.9 %.  The cost matrices of the loss section use the same core by default.
+// The 36 GEMMs on the bf16x3 core (mfma_x3.h) where the weights' x3 panels are given and the launch has at least
+// STROTSS_X3_MIN_TILES 128 x 128 output tiles (default 1024 = four rounds of the 256 CUs; with fewer -- idle CUs,
+// half-empty 128-row tiles -- the f32 core's smaller tiles win: 512-px scale 2.28 vs 2.41 ms/step).  The GEMMs run
+// 1.55x faster (512->512 @128x128 px: 172 -> 112 us, the layer 209 -> 153 us).  Default ON since round 2
+// (STROTSS_X3_CONV=0 switches it off): five alternating A/B runs of the 1024-px step on one box gave 5.294 +- 0.004 ms
+// (off) against 5.117 +- 0.010 ms (on), -3.4 % (profiles/r02_ab_x3conv.txt); round 1's four single runs on four boxes
+// (+2.8 %, +-0, -1.5 %, -1.9 %) were inside their own noise.  The cost matrices of the loss section use the same core.
 static bool x3_enabled(size_t T, int cout) {
   static int on = -1;
   static long min_tiles = 1024;
   if (on < 0) {
-    const char* c = getenv("STROTSS_X3_CONV"); on = c ? atoi(c) : 0;
+    const char* c = getenv("STROTSS_X3_CONV"); on = c ? atoi(c) : 1;
     const char* e = getenv("STROTSS_X3"); if (e && atoi(e) == 0) on = 0;
     const char* m = getenv("STROTSS_X3_MIN_TILES"); if (m) min_tiles = atol(m);
   }

@@ -144,7 +144,7 @@ def winograd_x3(u: torch.Tensor, h: int, w: int):
     rows = int(u.shape[1])
     tiles = -(-(-(-h // 4) * -(-w // 4)) // 128) * -(-rows // 128) * 36
     if int(u.shape[0]) != 36 or int(u.shape[2]) % 32 or os.environ.get("STROTSS_X3", "1") == "0" \
-            or os.environ.get("STROTSS_X3_CONV", "0") == "0":           # opt-in, see csrc/winograd.hip x3_enabled
+            or os.environ.get("STROTSS_X3_CONV", "1") == "0":           # default on, see csrc/winograd.hip x3_enabled
         return None
     if tiles < _x3_min_tiles() or (rows <= 256 and os.environ.get("STROTSS_WINO_FUSED", "1") != "0"):
         return None

@@ -48,7 +48,7 @@ def main():
     n_e = 5
     eng._graph = None                         # per-launch events need eager launches
     for i in range(n_e):
-        eng.step([idx[i]])
+        eng.step(list(idx[i]))
     torch.cuda.synchronize()
     agg = {}
     for name, shp, cout, a0, a1 in rec:

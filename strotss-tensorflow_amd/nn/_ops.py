@@ -127,6 +127,31 @@ def winograd_packed(u: torch.Tensor):
     return up
 
 
+_packed_x3 = {}    # id(u) -> (weakref(u), planes): split planes of frozen F(4x4,3x3) weights for the fused bf16x3 kernel
+
+
+def winograd_packed_x3(u: torch.Tensor):
+    """The h / m / l bf16 planes of a (36, rows, k) Winograd weight tensor in the fragment order of the fused bf16x3
+    kernel (csrc/winograd_fused_x3.hip; made once per tensor object), or None where that kernel does not apply."""
+    import os, weakref
+    if int(u.shape[0]) != 36 or int(u.shape[1]) % 32 or int(u.shape[2]) % 32 or int(u.shape[1]) > 256 \
+            or os.environ.get("STROTSS_X3", "1") == "0" or os.environ.get("STROTSS_WINO_FUSED_X3", "0") == "0" \
+            or os.environ.get("STROTSS_WINO_FUSED", "1") == "0":
+        return None
+    hit = _packed_x3.get(id(u))
+    if hit is not None and hit[0]() is u:
+        return hit[1]
+    require(u, "winograd weights")
+    rows, k = int(u.shape[1]), int(u.shape[2])
+    nb = _hip.lib().strotss_conv3x3_winograd_x3_bytes(rows, k)
+    up = torch.empty(nb // 2, dtype=torch.bfloat16, device=u.device)
+    check(_hip.lib().strotss_conv3x3_winograd_pack_x3(ptr(u), rows, k, ptr(up), stream_ptr()), "conv3x3_winograd_pack_x3")
+    for key in [key for key, v in _packed_x3.items() if v[0]() is None]:
+        del _packed_x3[key]
+    _packed_x3[id(u)] = (weakref.ref(u), up)
+    return up
+
+
 _x3 = {}           # id(u) -> (weakref(u), panels): bf16x3 "x3 panels" of frozen F(4x4,3x3) weights
 
 
@@ -172,7 +197,7 @@ def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None
     m = _tile_m(u_pok)
     ws, nb = _wino_ws(h, w, cin, cout, m, x.device)
     check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(winograd_packed(u_pok)),
-                                                  ptr(winograd_x3(u_pok, h, w)), ptr(bias),
+                                                  ptr(winograd_packed_x3(u_pok)), ptr(winograd_x3(u_pok, h, w)), ptr(bias),
                                                   cout, m, ptr(out), ptr(pool_out), ptr(pool_code), ptr(ws), nb, stream_ptr()),
           "conv3x3_winograd_fwd")
     return out
@@ -185,7 +210,7 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
     m = _tile_m(u_pik)
     ws, nb = _wino_ws(h, w, cout, cin, m, gout.device)
     check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), ptr(winograd_packed(u_pik)),
-                                                    ptr(winograd_x3(u_pik, h, w)), cin,
+                                                    ptr(winograd_packed_x3(u_pik)), ptr(winograd_x3(u_pik, h, w)), cin,
                                                     m, ptr(act_in), ptr(out), ptr(ws), nb, stream_ptr()),
           "conv3x3_winograd_dgrad")
     return out

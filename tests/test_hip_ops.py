@@ -449,15 +449,23 @@ def test_rmsprop_and_postprocess(ops):
     assert diff.max() <= 1 and (diff > 0).mean() < 0.01    # truncation boundary cases only
 
 
-def test_fused_winograd_kernel_on_every_shape():
+@pytest.mark.parametrize("variant", ["f32", "x3_in_registers", "x3_planes"])
+def test_fused_winograd_kernel_on_every_shape(variant):
     """The fused F(4x4,3x3) kernel is chosen by a size policy that the small shapes of this file never meet; force it
     (STROTSS_WINO_FUSED=2 is read once per process) and run the Winograd parity tests again in a child process:
-    odd sizes, 32..512 channels, forward with bias/ReLU and pooled copy, data-gradient with and without ReLU mask."""
+    odd sizes, 32..512 channels, forward with bias/ReLU and pooled copy, data-gradient with and without ReLU mask.
+    Variants: the default f32-MFMA products; the same kernel with the products on the bf16 MFMA, operands split
+    exactly in registers (STROTSS_WINO_FUSED_PROD=x3); the separate pre-split-planes kernel
+    (csrc/winograd_fused_x3.hip, STROTSS_WINO_FUSED_X3=1) -- both measured slower, kept as tested alternatives."""
     import os, subprocess, sys
     if os.environ.get("STROTSS_WINO_FUSED") == "2":
         pytest.skip("already inside the forced run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, STROTSS_WINO_FUSED="2")
+    if variant == "x3_in_registers":
+        env["STROTSS_WINO_FUSED_PROD"] = "x3"
+    if variant == "x3_planes":
+        env["STROTSS_WINO_FUSED_X3"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_ops.py"), "-q", "-x", "-m", "gpu",
                           "-k", "test_conv_winograd_fwd_and_dgrad"], env=env, cwd=root, capture_output=True, text=True,
                          timeout=600)

@@ -336,12 +336,38 @@ def wall_clock_to_output(dev, size=1024, level=5, max_iter=200):
             f"(scales 64..{64 << (level - 1)}), incl. VGG build, JPEG decode/encode, per-scale setup, hipGraph capture"}
 
 
+def usable_cores():
+    """Cores this process may actually run on: os.cpu_count() counts the whole host, the scheduler affinity mask and the
+    cgroup CPU quota say what the container gets (a GPU box of this pool reports 256 and grants 16: 256 torch threads on
+    16 cores ran the oracle 50x SLOWER than 16 threads)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(quota / int(g.read()) + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(scale, budget_s=25.0):
     """fp32 torch-CPU oracle (the restatement of the reference) on the same synthetic workload."""
     from oracle import strotss_oracle as O
     from nn.model import synthetic_weights
     host_cores = os.cpu_count() or 1
-    threads = int(os.environ.get("STROTSS_CPU_THREADS", "0")) or host_cores       # all host cores (BASELINE.md 3)
+    threads = int(os.environ.get("STROTSS_CPU_THREADS", "0")) or usable_cores()   # all cores this process is granted
     torch.set_num_threads(threads)
     weights = synthetic_weights('16', 0)
     vgg = O.VGG(weights, dtype=torch.float32)
@@ -374,9 +400,10 @@ def cpu_baseline(scale, budget_s=25.0):
             t_total += one_step()
             timed += 1
     out = {"value": round(timed / t_total, 5), "unit": "steps/s", "cores": threads, "kind": "port",
-           "host_cpu_count": host_cores,
+           "host_cpu_count": host_cores, "usable_cores": usable_cores(),
            "sample": f"{timed} step(s) of the {scale}x{scale} scale (1024 samples) {note}, fp32 torch-CPU "
-                     f"oracle with {threads} threads = os.cpu_count() of this host unless STROTSS_CPU_THREADS is set "
+                     f"oracle with {threads} threads = every core this process is granted (os.cpu_count() = {host_cores} "
+                     f"on the host, affinity mask / cgroup quota = {usable_cores()}; STROTSS_CPU_THREADS overrides) "
                      f"(the reference pins TF to 1 thread, nn/rand.py:16-17: see one_thread)"}
     # the reference's own setting (1 inter-op + 1 intra-op thread, nn/rand.py:16-17): ONE step of the same workload
     # when the multi-threaded rate says it fits the budget (SURVEY.md 8d asks for both)

@@ -573,9 +573,25 @@ int st_cosine_distance_x3(const void* xp, const float* rx, int nx, const void* y
                           long long cstride, hipStream_t s) {
   using Cfg = X3Cfg<64>;
   EpiCosDistX3 e{{rx, ry, C, ldc, nx, ny, symm}, {}, rstride, cstride};
-  const unsigned g = cdiv(nx, 64);
-  dim3 grid((symm ? g * (g + 1) / 2 : (unsigned)cdiv(ny, 64) * g) * batch);
+  const unsigned g = cdiv(nx, 64), gxn = cdiv(ny, 64);
+  dim3 grid((symm ? g * (g + 1) / 2 : gxn * g) * batch);
+  // 2-D XCD blocking of the full (non-symmetric) product when the tile grid splits evenly over the 8 XCDs: block of
+  // bh x bw tiles per XCD with bh * bw = tiles / 8, as square as the divisibility allows (STROTSS_X3_XCD_BLOCK=0: rows)
+  int bh = 0, bw = 0;
+  static int blocking = -1;
+  if (blocking < 0) { const char* ev = getenv("STROTSS_X3_XCD_BLOCK"); blocking = ev ? atoi(ev) : 1; }
+  if (!symm && blocking && (gxn * g) % 8 == 0) {
+    const unsigned per = gxn * g / 8;
+    unsigned best = 0;
+    for (unsigned h = 1; h <= per; ++h) {
+      if (per % h || g % h) continue;
+      const unsigned w = per / h;
+      if (gxn % w) continue;
+      if (!best || h + w < best + per / best) best = h;
+    }
+    if (best) { bh = (int)best; bw = (int)(per / best); }
+  }
   hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiCosDistX3, X3Mirror<Cfg>>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)xp, nx,
-                     pstride, (const __bf16*)yp, ny, pstride, K, e, X3Mirror<Cfg>{});
+                     pstride, (const __bf16*)yp, ny, pstride, K, e, X3Mirror<Cfg>{}, bh, bw);
   ST_LAUNCH_RET();
 }

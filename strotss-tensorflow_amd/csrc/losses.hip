@@ -63,22 +63,45 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ 
 
 // self_similarity (losses.py:55-66) on the TRANSPOSED matrices: the cosine matrices are bitwise
 // symmetric (gemm.hip), so column j of D / colsum[j] == row j of D / rowsum[j].
-// Row j:  A' = Dx[j,:]/sx_j, B' = Dy[j,:]/sy_j, loss_j = sum |A'-B'|, S' = sign(A'-B') * sscale,
-//         t_j = sum S' A' (0 when the clamp is active), Q[j,:] = (S' - t_j)/sx_j  (= dL/dDx[:,j]).
-__global__ __launch_bounds__(256) void selfsim_rowpass_kernel(const float* __restrict__ Dx,
-                                                              const float* __restrict__ Dy,
-                                                              const float* __restrict__ sx_raw,
-                                                              const float* __restrict__ sy_raw, int n,
-                                                              int ldc, float sscale, float* __restrict__ Q,
+// Row j, ONE pass over its two rows (held in registers up to n = 1024, re-read beyond):
+//   sx_j = sum Dx[j,:], sy_j likewise;  A' = Dx[j,:]/sx_j, B' = Dy[j,:]/sy_j, loss_j = sum |A'-B'|,
+//   S' = sign(A'-B') * sscale,  t_j = sum S' A' (0 when the clamp is active).
+// Out: isx[j] = 1/max(sx_j, 1e-12), isy[j], t[j], lossrow[j] -- all the backward needs of row j:
+//   dL/dDx[:,j] = Q[j,:] = (S' - t_j) * isx_j   is recomputed where it is used (selfsim_sym_kernel), never stored.
+#define SS_REG 4
+__global__ __launch_bounds__(256) void selfsim_rowstat_kernel(const float* __restrict__ Dx,
+                                                              const float* __restrict__ Dy, int n, int ldc,
+                                                              float sscale, float* __restrict__ isx_out,
+                                                              float* __restrict__ isy_out, float* __restrict__ t_out,
                                                               float* __restrict__ lossrow) {
   __shared__ float red[4];
   const int j = blockIdx.x;
-  const float sxr = sx_raw[j], syr = sy_raw[j];
-  const float isx = 1.0f / fmaxf(sxr, 1e-12f), isy = 1.0f / fmaxf(syr, 1e-12f);
   const float* px = Dx + (size_t)j * ldc;
   const float* py = Dy + (size_t)j * ldc;
+  float vx[SS_REG], vy[SS_REG];
+  float sxr = 0.f, syr = 0.f;
+#pragma unroll
+  for (int k = 0; k < SS_REG; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    vx[k] = i < n ? px[i] : 0.f;
+    vy[k] = i < n ? py[i] : 0.f;
+    sxr += vx[k]; syr += vy[k];
+  }
+  for (int i = threadIdx.x + 256 * SS_REG; i < n; i += 256) { sxr += px[i]; syr += py[i]; }
+  sxr = block_sum_256(sxr, red);
+  syr = block_sum_256(syr, red);
+  const float isx = 1.0f / fmaxf(sxr, 1e-12f), isy = 1.0f / fmaxf(syr, 1e-12f);
   float l = 0.f, t = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+  for (int k = 0; k < SS_REG; ++k) {
+    if (threadIdx.x + 256 * k < n) {
+      const float a = vx[k] * isx, b = vy[k] * isy;
+      const float d = a - b;
+      l += fabsf(d);
+      t += signf(d) * sscale * a;
+    }
+  }
+  for (int i = threadIdx.x + 256 * SS_REG; i < n; i += 256) {
     const float a = px[i] * isx, b = py[i] * isy;
     const float d = a - b;
     l += fabsf(d);
@@ -87,30 +110,35 @@ __global__ __launch_bounds__(256) void selfsim_rowpass_kernel(const float* __res
   l = block_sum_256(l, red);
   t = block_sum_256(t, red);
   if (!(sxr >= 1e-12f)) t = 0.f;
-  float* q = Q + (size_t)j * ldc;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float a = px[i] * isx, b = py[i] * isy;
-    q[i] = (signf(a - b) * sscale - t) * isx;
-  }
-  if (threadIdx.x == 0) lossrow[j] = l;
+  if (threadIdx.x == 0) { isx_out[j] = isx; isy_out[j] = isy; t_out[j] = t; lossrow[j] = l; }
 }
 
-// M[i,j] = -(Q[i,j] + Q[j,i]);  Mq[i,j] = M[i,j] * r[j] (zero for n <= j < kpad);
-// qdot[i] = sum_j M[i,j] (1 - Dx[i,j])   (= xhat_i . dL/dxhat_i)
-__global__ __launch_bounds__(256) void selfsim_sym_kernel(const float* __restrict__ Q,
-                                                          const float* __restrict__ Dx,
-                                                          const float* __restrict__ r, int n, int ldc,
-                                                          int kpad, float* __restrict__ Mq,
-                                                          float* __restrict__ qdot, __bf16* __restrict__ Mp) {
+// M[i,j] = -(Q[i,j] + Q[j,i]) with Q[i,j] = (sign(Dx[i,j] isx_i - Dy[i,j] isy_i) sscale - t_i) isx_i and, the cosine
+// matrices being bitwise symmetric, Q[j,i] from the SAME two entries with row j's statistics: one coalesced pass over
+// rows i of Dx and Dy, no N x N intermediate.  Mq[i,j] = M[i,j] * r[j] (zero for n <= j < kpad);
+// qdot[i] = sum_j M[i,j] (1 - Dx[i,j])   (= xhat_i . dL/dxhat_i).  Workgroup 0 also reduces the rows' losses:
+// loss_out[0] = loss_scale * sum_j lossrow[j] (fixed order).
+__global__ __launch_bounds__(256) void selfsim_sym_kernel(const float* __restrict__ Dx, const float* __restrict__ Dy,
+                                                          const float* __restrict__ isx, const float* __restrict__ isy,
+                                                          const float* __restrict__ tt, const float* __restrict__ r,
+                                                          int n, int ldc, int kpad, float sscale,
+                                                          float* __restrict__ Mq, float* __restrict__ qdot,
+                                                          __bf16* __restrict__ Mp, const float* __restrict__ lossrow,
+                                                          float loss_scale, float* __restrict__ loss_out) {
   // Mp != NULL: Mq goes out as x3 panels (rows = n, K = kpad; mfma_x3.h) for the bf16x3 backward GEMM instead
   __shared__ float red[4];
   const int i = blockIdx.x;
+  const float isx_i = isx[i], isy_i = isy[i], t_i = tt[i];
   float acc = 0.f;
   for (int j = threadIdx.x; j < kpad; j += 256) {
     float out = 0.f;
     if (j < n) {
-      const float m = -(Q[(size_t)i * ldc + j] + Q[(size_t)j * ldc + i]);
-      acc += m * (1.0f - Dx[(size_t)i * ldc + j]);
+      const float dx = Dx[(size_t)i * ldc + j], dy = Dy[(size_t)i * ldc + j];
+      const float isx_j = isx[j];
+      const float q_ij = (signf(dx * isx_i - dy * isy_i) * sscale - t_i) * isx_i;
+      const float q_ji = (signf(dx * isx_j - dy * isy[j]) * sscale - tt[j]) * isx_j;
+      const float m = -(q_ij + q_ji);
+      acc += m * (1.0f - dx);
       out = m * r[j];
     }
     if (Mp) {
@@ -125,6 +153,12 @@ __global__ __launch_bounds__(256) void selfsim_sym_kernel(const float* __restric
   }
   acc = block_sum_256(acc, red);
   if (threadIdx.x == 0) qdot[i] = acc;
+  if (i == 0) {
+    float a = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) a += lossrow[j];
+    a = block_sum_256(a, red);
+    if (threadIdx.x == 0) loss_out[0] = a * loss_scale;
+  }
 }
 
 // out[0] = scale * sum(partial[0..count))      (single block, fixed order)
@@ -193,33 +227,52 @@ __global__ __launch_bounds__(256) void row_col_min_kernel(const float* __restric
     col_min_partial_block(C, bb % gx, bb / gx, rows, n, ldc, pmin, pcnt);
   }
 }
-// Stage 2 of the column minima + the choice of the REMD branch, one workgroup:
+// Stage 2 of the column minima + the choice of the REMD branch, one workgroup of 1024 threads (a column per thread:
+// its 2 x COL_CHUNKS partials are all in flight at once):
 //   cmin[j] = min over the chunks, ccnt[j] = count of the minimum;
 //   loss = max(R_X, R_Y) with R_X = mean of `xmin` (minima per style row), R_Y = mean of the minima per prediction
 //   row; sel[0] = 1 when the R_X branch carries the gradient (tf.maximum: first argument on ties).
 // col_is_x: the column minima are the R_X side (pred-major cost matrix of the cosine REMD), else the R_Y side.
-__global__ __launch_bounds__(256) void col_min_final_select_kernel(const float* __restrict__ pmin,
-                                                                   const float* __restrict__ pcnt, int n, int ldc,
-                                                                   float* __restrict__ cmin, float* __restrict__ ccnt,
-                                                                   const float* __restrict__ rowmin, int rows,
-                                                                   int col_is_x, float* __restrict__ loss_out,
-                                                                   int* __restrict__ sel) {
-  __shared__ float red[4];
+// pmin == NULL: cmin / ccnt are final already (palette: computed directly), only the means and the branch are taken.
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {     // fixed order
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a += red[k];
+  return a;
+}
+__global__ __launch_bounds__(1024) void col_min_final_select_kernel(const float* __restrict__ pmin,
+                                                                    const float* __restrict__ pcnt, int n, int ldc,
+                                                                    float* __restrict__ cmin, float* __restrict__ ccnt,
+                                                                    const float* __restrict__ rowmin, int rows,
+                                                                    int col_is_x, float* __restrict__ loss_out,
+                                                                    int* __restrict__ sel) {
+  __shared__ float red[16];
   float a = 0.f, b = 0.f;
-  for (int j = threadIdx.x; j < n; j += 256) {
-    float m = INFINITY;
+  for (int j = threadIdx.x; j < n; j += 1024) {
+    if (pmin) {
+      float pm[COL_CHUNKS], pc[COL_CHUNKS];
 #pragma unroll
-    for (int k = 0; k < COL_CHUNKS; ++k) m = fminf(m, pmin[(size_t)k * ldc + j]);
-    float cnt = 0.f;
+      for (int k = 0; k < COL_CHUNKS; ++k) { pm[k] = pmin[(size_t)k * ldc + j]; pc[k] = pcnt[(size_t)k * ldc + j]; }
+      float m = INFINITY;
 #pragma unroll
-    for (int k = 0; k < COL_CHUNKS; ++k) cnt += (pmin[(size_t)k * ldc + j] == m) ? pcnt[(size_t)k * ldc + j] : 0.f;
-    cmin[j] = m;
-    ccnt[j] = cnt;
-    a += m;
+      for (int k = 0; k < COL_CHUNKS; ++k) m = fminf(m, pm[k]);
+      float cnt = 0.f;
+#pragma unroll
+      for (int k = 0; k < COL_CHUNKS; ++k) cnt += (pm[k] == m) ? pc[k] : 0.f;
+      cmin[j] = m;
+      ccnt[j] = cnt;
+      a += m;
+    } else {
+      a += cmin[j];
+    }
   }
-  for (int i = threadIdx.x; i < rows; i += 256) b += rowmin[i];
-  a = block_sum_256(a, red);
-  b = block_sum_256(b, red);
+  for (int i = threadIdx.x; i < rows; i += 1024) b += rowmin[i];
+  a = block_sum_1024(a, red);
+  b = block_sum_1024(b, red);
   if (threadIdx.x == 0) {
     const float mc = a / (float)n, mr = b / (float)rows;
     const float rx = col_is_x ? mc : mr, ry = col_is_x ? mr : mc;
@@ -320,20 +373,46 @@ __device__ __forceinline__ void palette_pair(const f32x4 a, const f32x4 b, float
   const float ys = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
   m = xs + ys - 2.0f * dot;                        // losses.py:22
 }
-// C[i,j] = cosine + sqrt(max(m,1e-6)/3)           dist_metrics['both'] (losses.py:27-28)
-__global__ __launch_bounds__(256) void palette_cost_kernel(const f32x4* __restrict__ ys, int ns,
-                                                           const f32x4* __restrict__ yp, int n,
-                                                           float* __restrict__ C, int ldc) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const int i = blockIdx.y;
-  if (j >= n) return;
-  float cc, m;
-  palette_pair(ys[i], yp[j], cc, m);
-  C[(size_t)i * ldc + j] = cc + sqrtf(fmaxf(m, 1e-6f) / 3.0f);
+// C[i,j] = cosine + sqrt(max(m,1e-6)/3)           dist_metrics['both'] (losses.py:27-28).  The N_s x N matrix is never
+// stored: the minima kernel and the backward kernel both evaluate this ONE function on the same operands in the same
+// order, so `cost == minimum` compares bitwise equal values in both.
+__device__ __forceinline__ float palette_cost(const f32x4 x, const f32x4 y, float& ccos, float& m) {
+  palette_pair(x, y, ccos, m);
+  return ccos + sqrtf(fmaxf(m, 1e-6f) / 3.0f);
+}
+// Minima and their multiplicities, rows and columns in ONE launch: workgroup b < ns takes style row b (minimum over
+// the predictions j), workgroup ns + j the prediction j (minimum over the style rows i).
+__global__ __launch_bounds__(256) void palette_minima_kernel(const f32x4* __restrict__ ys, int ns,
+                                                             const f32x4* __restrict__ yp, int n,
+                                                             float* __restrict__ rmin, float* __restrict__ rcnt,
+                                                             float* __restrict__ cmin, float* __restrict__ ccnt) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const bool row = b < ns;
+  const f32x4 mine = row ? ys[b] : yp[b - ns];
+  const f32x4* other = row ? yp : ys;
+  const int cnt_other = row ? n : ns;
+  float mn = INFINITY;
+  for (int k = threadIdx.x; k < cnt_other; k += 256) {
+    float cc, m;
+    const f32x4 o = other[k];
+    mn = fminf(mn, row ? palette_cost(mine, o, cc, m) : palette_cost(o, mine, cc, m));
+  }
+  mn = block_min_256(mn, red);
+  float c = 0.f;
+  for (int k = threadIdx.x; k < cnt_other; k += 256) {
+    float cc, m;
+    const f32x4 o = other[k];
+    c += ((row ? palette_cost(mine, o, cc, m) : palette_cost(o, mine, cc, m)) == mn) ? 1.f : 0.f;
+  }
+  c = block_sum_256(c, red);
+  if (threadIdx.x == 0) {
+    if (row) { rmin[b] = mn; rcnt[b] = c; } else { cmin[b - ns] = mn; ccnt[b - ns] = c; }
+  }
 }
 // One wave per pred sample j.
 __global__ __launch_bounds__(64) void palette_bwd_kernel(
-    const float* __restrict__ C, int ldc, const f32x4* __restrict__ ys, int ns, const f32x4* __restrict__ yp,
+    const f32x4* __restrict__ ys, int ns, const f32x4* __restrict__ yp,
     int n, const float* __restrict__ rmin, const float* __restrict__ rcnt, const float* __restrict__ cmin,
     const float* __restrict__ ccnt, const int* __restrict__ sel, float gscale, float* __restrict__ gpred,
     int ld, int convert) {
@@ -343,13 +422,12 @@ __global__ __launch_bounds__(64) void palette_bwd_kernel(
   const float cm = cmin[j], cc = ccnt[j];
   float gh0 = 0.f, gh1 = 0.f, gh2 = 0.f, q = 0.f, sk = 0.f, kx0 = 0.f, kx1 = 0.f, kx2 = 0.f;
   for (int i = lane; i < ns; i += 64) {
-    const float v = C[(size_t)i * ldc + j];
+    const f32x4 x = ys[i];
+    float ccos, m;
+    const float v = palette_cost(x, y, ccos, m);
     const bool hit = row_branch ? (v == rmin[i]) : (v == cm);
     if (hit) {
       const float w = row_branch ? 1.0f / ((float)ns * rcnt[i]) : 1.0f / ((float)n * cc);
-      const f32x4 x = ys[i];
-      float ccos, m;
-      palette_pair(x, y, ccos, m);
       const float wr = w * x[3];
       gh0 -= wr * x[0]; gh1 -= wr * x[1]; gh2 -= wr * x[2];
       q -= w * (1.0f - ccos);
@@ -608,7 +686,7 @@ bool cost_x3() {
 }
 
 struct SelfsimWs {
-  float *rp, *rc, *Dx, *Dy, *sx, *sy, *Q, *Mq, *qdot, *lossrow;
+  float *rp, *rc, *Dx, *Dy, *sx, *sy, *tt, *Mq, *qdot, *lossrow;
   __bf16 *xp, *xc;               // x3 panels of pred / content (ld > 0)
   __bf16 *xt, *mp;               // x3 panels of pred transposed (rows = ld, K = ldc) and of Mq (rows = n, K = ldc)
   int ldc;
@@ -618,8 +696,8 @@ struct SelfsimWs {
     xt = w.take<__bf16>((size_t)3 * ld * ldc); mp = w.take<__bf16>((size_t)3 * n * ldc);
     rp = w.take<float>(ldc); rc = w.take<float>(ldc);
     Dx = w.take<float>((size_t)n * ldc); Dy = w.take<float>((size_t)n * ldc);
-    sx = w.take<float>(ldc); sy = w.take<float>(ldc);
-    Q = w.take<float>((size_t)n * ldc); Mq = w.take<float>((size_t)n * ldc);
+    sx = w.take<float>(ldc); sy = w.take<float>(ldc); tt = w.take<float>(ldc);
+    Mq = w.take<float>((size_t)n * ldc);
     qdot = w.take<float>(ldc); lossrow = w.take<float>(ldc);
     return w.ok();
   }
@@ -741,14 +819,13 @@ int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int 
     CHK(st_cosine_distance(pred, s.rp, n, pred, s.rp, n, ld, s.Dx, ldc, st));
     CHK(st_cosine_distance(content, s.rc, n, content, s.rc, n, ld, s.Dy, ldc, st));
   }
-  hipLaunchKernelGGL(row_sum_kernel, dim3(n, 2), dim3(256), 0, st, s.Dx, n, ldc, s.sx, s.Dy, s.sy);
-  // loss = mean(|A-B|) * n = (1/n) sum |A-B|  ->  dL/dA = sign/n
-  hipLaunchKernelGGL(selfsim_rowpass_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, n, ldc,
-                     1.0f / (float)n, s.Q, s.lossrow);
+  // loss = mean(|A-B|) * n = (1/n) sum |A-B|  ->  dL/dA = sign/n.  Two passes over the two matrices in all: the rows'
+  // statistics (sx and sy hold the RECIPROCAL clamped row sums), then the symmetrised gradient + the loss
+  hipLaunchKernelGGL(selfsim_rowstat_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, n, ldc, 1.0f / (float)n, s.sx, s.sy,
+                     s.tt, s.lossrow);
   const bool bx3 = cost_x3();
-  hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st, s.Q, s.Dx, s.rp, n, ldc, ldc, s.Mq,
-                     s.qdot, bx3 ? s.mp : (__bf16*)nullptr);
-  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, s.lossrow, n, 1.0f / (float)n, loss_out);
+  hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, s.tt, s.rp, n, ldc, ldc,
+                     1.0f / (float)n, s.Mq, s.qdot, bx3 ? s.mp : (__bf16*)nullptr, s.lossrow, 1.0f / (float)n, loss_out);
   if (bx3)
     hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, ldc / 32), dim3(256), 0, st, pred, n, ldc, ld, (const float*)nullptr,
                        (__bf16*)nullptr, s.xt);
@@ -839,7 +916,6 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   RemdWs s;
   ST_CHECK_ARG(s.plan(w, ns, n, ld), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
-  const int ldc = s.ldc;
   const bool x3 = cost_x3();
   if (x3) {
     hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n > ns ? n : ns, 4), 2), dim3(256), 0, st, pred, n, ld, s.rp, s.xp,
@@ -856,7 +932,7 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   else CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.C, ldt, st));
   hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.cmin,
                      s.ccnt, s.pmin, s.pcnt);
-  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(256), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin, s.rcnt,
+  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin, s.rcnt,
                      s.cmin, n, 1, loss_out, s.sel);
   hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldt, style, rs, ns, pred, s.rp, n,
                      ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
@@ -871,16 +947,14 @@ int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, 
   RemdWs s;
   ST_CHECK_ARG(s.plan(w, ns, n, 0), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
-  const int ldc = s.ldc;
   hipLaunchKernelGGL(palette_prepare_kernel, dim3(cdiv(n > ns ? n : ns, 256), 2), dim3(256), 0, st, style, ns, ld, s.ys,
                      rgb_to_yuv, pred, n, s.yp);
-  hipLaunchKernelGGL(palette_cost_kernel, dim3(cdiv(n, 256), ns), dim3(256), 0, st, s.ys, ns, s.yp, n, s.C,
-                     ldc);
-  hipLaunchKernelGGL(row_col_min_kernel, dim3(ns + cdiv(n, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, ns, n, ldc, s.rmin,
-                     s.rcnt, s.pmin, s.pcnt);
-  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(256), 0, st, s.pmin, s.pcnt, n, ldc, s.cmin, s.ccnt,
-                     s.rmin, ns, 0, loss_out, s.sel);
-  hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, s.C, ldc, s.ys, ns, s.yp, n, s.rmin,
+  // no N_s x N matrix: the minima kernel and the backward kernel evaluate the 3-channel cost on the fly (bitwise alike)
+  hipLaunchKernelGGL(palette_minima_kernel, dim3(ns + n), dim3(256), 0, st, s.ys, ns, s.yp, n, s.rmin, s.rcnt, s.cmin,
+                     s.ccnt);
+  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, (const float*)nullptr, (const float*)nullptr,
+                     n, 0, s.cmin, s.ccnt, s.rmin, ns, 0, loss_out, s.sel);
+  hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, s.ys, ns, s.yp, n, s.rmin,
                      s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred, ld, rgb_to_yuv);
   ST_LAUNCH_RET();
 }

@@ -226,7 +226,7 @@ struct X3NoPrefetch {
 template <class Cfg, class Epi, class Mirror>
 __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restrict__ A, int M, long long strideA,
                                                           const __bf16* __restrict__ B, int N, long long strideB,
-                                                          int K, Epi epi, Mirror mirror) {
+                                                          int K, Epi epi, Mirror mirror, int xbh = 0, int xbw = 0) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDS_BYTES];
   const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
   unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -246,7 +246,17 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
   } else {
     bz = tile / (gx * gy);
     const unsigned rem = tile - bz * (gx * gy);
-    m0 = (rem / gx) * Cfg::BM; n0 = (rem % gx) * Cfg::BN;
+    if (xbh > 0) {
+      // 2-D XCD blocking: the launch order gives every XCD a contiguous run of xbh * xbw tile ids; lay each run out as
+      // an xbh x xbw BLOCK of the tile grid instead of xbh * xbw / gx whole rows, so the XCD's L2 streams xbh A panels
+      // and xbw B panels (16 x 16 tiles: 4 + 8 = 12 panels instead of 2 + 16 = 18)
+      const unsigned per = (unsigned)(xbh * xbw), blk = rem / per, in = rem - blk * per;
+      const unsigned bpr = gx / (unsigned)xbw;                     // blocks per block-row
+      const unsigned ty = (blk / bpr) * xbh + in / xbw, tx = (blk % bpr) * xbw + in % xbw;
+      m0 = ty * Cfg::BM; n0 = tx * Cfg::BN;
+    } else {
+      m0 = (rem / gx) * Cfg::BM; n0 = (rem % gx) * Cfg::BN;
+    }
   }
   epi.set_batch(bz);
   X3Operand<Cfg::G, 3> oa(A + (long long)bz * strideA, M, m0);

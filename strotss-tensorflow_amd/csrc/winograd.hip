@@ -286,11 +286,24 @@ static bool x3_enabled(size_t T, int cout) {
   return on != 0 && (long)((T + 127) / 128) * ((cout + 127) / 128) * 36 >= min_tiles;
 }
 
+static int x3_min_cout() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("STROTSS_X3_MIN_COUT"); v = e ? atoi(e) : 256; }
+  return v;
+}
+// layers the fused kernel could take but the three-kernel form with bf16x3 GEMMs runs faster
+static bool winograd43_prefers_x3(int h, int w, int cout) {
+  return cout >= x3_min_cout() && x3_enabled((size_t)((h + 3) / 4) * ((w + 3) / 4), cout);
+}
+
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* Upacked,
                           const void* Upacked_x3, const void* Ux3, const float* bias, int cout, const float* mask, int relu, float* out,
                           float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
                           hipStream_t st) {
-  if ((Upacked || Upacked_x3) && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout)) {   // everything on chip
+  // 256 output channels and enough tiles for the bf16x3 GEMMs: the three-kernel form wins (1024-px step 5.102 -> 5.039 ms,
+  // three alternating runs each); STROTSS_X3_MIN_COUT (default 256) moves the border
+  const bool prefer_x3 = Ux3 && cin % 32 == 0 && winograd43_prefers_x3(h, w, cout);
+  if (!prefer_x3 && (Upacked || Upacked_x3) && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout)) {   // everything on chip
     if (Upacked_x3 && st_winograd43_fused_x3_enabled())
       return st_winograd43_fused_x3(in, h, w, cin, Upacked_x3, bias, cout, mask, relu, out, pool_out, pool_code, st);
     if (Upacked) return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, st);
@@ -380,8 +393,9 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   ST_CHECK_ARG(!pool_out || (h >= 2 && w >= 2), STROTSS_EINVAL);
   ST_CHECK_ARG(!pool_code || pool_out, STROTSS_EINVAL);
-  const bool fused = tile_m == 4 && (u_packed || (u_packed_x3 && st_winograd43_fused_x3_enabled())) && cin % 32 == 0 &&
-                     st_winograd43_fused_enabled(h, w, cout);
+  bool fused = tile_m == 4 && (u_packed || (u_packed_x3 && st_winograd43_fused_x3_enabled())) && cin % 32 == 0 &&
+               st_winograd43_fused_enabled(h, w, cout);
+  if (fused && u_x3 && winograd43_prefers_x3(h, w, cout)) fused = false;
   int rc;
   if (tile_m == 4)
     rc = winograd43_run(in, h, w, cin, u_pok, u_packed, u_packed_x3, u_x3, bias, cout, nullptr, 1, out, pool_out, pool_code, workspace,

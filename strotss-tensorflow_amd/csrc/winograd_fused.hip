@@ -481,9 +481,12 @@ bool st_winograd43_fused_enabled(int h, int w, int cout) {
   if (on >= 2) return true;
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const long items = (long)((TH + F_TR - 1) / F_TR) * ((TW + F_TC - 1) / F_TC) * (cout / 32);
-  static long min_items = -1;
-  if (min_items < 0) { const char* e = getenv("STROTSS_WINO_FUSED_MIN_ITEMS"); min_items = e ? atol(e) : 128; }
-  return cout <= 256 && items >= min_items;
+  static long min_items = -1, max_cout = 256;
+  if (min_items < 0) {
+    const char* e = getenv("STROTSS_WINO_FUSED_MIN_ITEMS"); min_items = e ? atol(e) : 128;
+    const char* c = getenv("STROTSS_WINO_FUSED_MAX_COUT"); if (c) max_cout = atol(c);
+  }
+  return cout <= max_cout && items >= min_items;
 }
 
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,

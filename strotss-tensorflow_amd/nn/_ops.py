@@ -171,7 +171,10 @@ def winograd_x3(u: torch.Tensor, h: int, w: int):
     if int(u.shape[0]) != 36 or int(u.shape[2]) % 32 or os.environ.get("STROTSS_X3", "1") == "0" \
             or os.environ.get("STROTSS_X3_CONV", "1") == "0":           # default on, see csrc/winograd.hip x3_enabled
         return None
-    if tiles < _x3_min_tiles() or (rows <= 256 and os.environ.get("STROTSS_WINO_FUSED", "1") != "0"):
+    fused_takes_it = (rows <= int(os.environ.get("STROTSS_WINO_FUSED_MAX_COUT", "256"))
+                      and rows < int(os.environ.get("STROTSS_X3_MIN_COUT", "256"))
+                      and os.environ.get("STROTSS_WINO_FUSED", "1") != "0")
+    if tiles < _x3_min_tiles() or fused_takes_it:
         return None
     hit = _x3.get(id(u))
     if hit is not None and hit[0]() is u:

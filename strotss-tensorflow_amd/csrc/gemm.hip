@@ -387,13 +387,22 @@ struct X3Mirror {       // writes the transpose of the workgroup's tile through 
 };
 
 // C[z] (M x N, ldc) = A[z] B[z]^T, both operands as x3 panels of K columns (K % 32 == 0).
+// 128 x 128 tiles (one workgroup per CU) when there are at least `min_tiles128` of them, else 64 x 64 (two per CU): few
+// big tiles leave CUs idle (36 x (256 x 512 x 512): 288 big tiles on 256 CUs = 2 rounds of 1.1, 1152 small ones fill it).
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
-                       int batch, hipStream_t s) {
-  using Cfg = X3Cfg<128>;
+                       int batch, hipStream_t s, long min_tiles128) {
   EpiScaleStoreX3 e{{C, ldc, M, N, 1.0f, strideC}, {}};
-  dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
-  hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStoreX3, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
-                     (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e, X3NoMirror{});
+  if ((long)cdiv(N, 128) * cdiv(M, 128) * batch >= min_tiles128) {
+    using Cfg = X3Cfg<128>;
+    dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
+    hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStoreX3, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
+                       (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e, X3NoMirror{});
+  } else {
+    using Cfg = X3Cfg<64>;
+    dim3 grid((unsigned)cdiv(N, 64) * cdiv(M, 64) * batch);
+    hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStoreX3, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
+                       (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e, X3NoMirror{});
+  }
   ST_LAUNCH_RET();
 }
 

@@ -42,7 +42,7 @@ int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp
 int st_moment_bwd_x3(const void* Pc, int n, int ld, const void* Tp, float alpha, const float* bias, float bias_scale,
                      float* dY, hipStream_t s);
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
-                       int batch, hipStream_t s);
+                       int batch, hipStream_t s, long min_tiles128 = 0);
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

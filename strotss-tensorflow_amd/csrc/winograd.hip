@@ -275,15 +275,20 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
 // (STROTSS_X3_CONV=0 switches it off): five alternating A/B runs of the 1024-px step on one box gave 5.294 +- 0.004 ms
 // (off) against 5.117 +- 0.010 ms (on), -3.4 % (profiles/r02_ab_x3conv.txt); round 1's four single runs on four boxes
 // (+2.8 %, +-0, -1.5 %, -1.9 %) were inside their own noise.  The cost matrices of the loss section use the same core.
+static long x3_min_tiles() {
+  static long min_tiles = -1;
+  if (min_tiles < 0) { const char* m = getenv("STROTSS_X3_MIN_TILES"); min_tiles = m ? atol(m) : 1024; }
+  return min_tiles;
+}
+// with fewer than STROTSS_X3_MIN_TILES 128 x 128 tiles the GEMMs run on 64 x 64 tiles (two workgroups per CU) as long
+// as there are that many of THOSE (block5 at 1024 px, block4 at 512 px: 36 x (256 x 512 x 512) = 1152 small tiles)
 static bool x3_enabled(size_t T, int cout) {
   static int on = -1;
-  static long min_tiles = 1024;
   if (on < 0) {
     const char* c = getenv("STROTSS_X3_CONV"); on = c ? atoi(c) : 1;
     const char* e = getenv("STROTSS_X3"); if (e && atoi(e) == 0) on = 0;
-    const char* m = getenv("STROTSS_X3_MIN_TILES"); if (m) min_tiles = atol(m);
   }
-  return on != 0 && (long)((T + 127) / 128) * ((cout + 127) / 128) * 36 >= min_tiles;
+  return on != 0 && (long)((T + 63) / 64) * ((cout + 63) / 64) * 36 >= x3_min_tiles();
 }
 
 static int x3_min_cout() {
@@ -291,9 +296,11 @@ static int x3_min_cout() {
   if (v < 0) { const char* e = getenv("STROTSS_X3_MIN_COUT"); v = e ? atoi(e) : 256; }
   return v;
 }
-// layers the fused kernel could take but the three-kernel form with bf16x3 GEMMs runs faster
+// layers the fused kernel could take but the three-kernel form with bf16x3 GEMMs runs faster: 256 output channels with
+// enough 128 x 128 GEMM tiles (block3 at 1024 px: step 5.06 -> 4.99 ms; at 512 px the fused kernel wins, 1.99 vs 2.03 ms)
 static bool winograd43_prefers_x3(int h, int w, int cout) {
-  return cout >= x3_min_cout() && x3_enabled((size_t)((h + 3) / 4) * ((w + 3) / 4), cout);
+  const size_t T = (size_t)((h + 3) / 4) * ((w + 3) / 4);
+  return cout >= x3_min_cout() && x3_enabled(T, cout) && (long)((T + 127) / 128) * ((cout + 127) / 128) * 36 >= x3_min_tiles();
 }
 
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* Upacked,
@@ -321,7 +328,7 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
     const size_t tin = ((T + 7) / 8) * 8 * (cin / 4);
     hipLaunchKernelGGL(winograd43_in_x3_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
                        in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V));
-    rc = st_gemm_x3_batched(V, Ux3, Mw, cout, (long long)T * cout, (int)T, cout, cin, 36, st);
+    rc = st_gemm_x3_batched(V, Ux3, Mw, cout, (long long)T * cout, (int)T, cout, cin, 36, st, x3_min_tiles());
   } else {
     const size_t tin = T * (cin / 4);
     hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,

@@ -167,12 +167,13 @@ def winograd_x3(u: torch.Tensor, h: int, w: int):
     STROTSS_X3_MIN_TILES 128 x 128 GEMM tiles) on the layers the fused kernel does not take (rows > 256)."""
     import os, weakref
     rows = int(u.shape[1])
-    tiles = -(-(-(-h // 4) * -(-w // 4)) // 128) * -(-rows // 128) * 36
+    tiles = -(-(-(-h // 4) * -(-w // 4)) // 64) * -(-rows // 64) * 36       # 64 x 64 tiles (csrc/winograd.hip x3_enabled)
     if int(u.shape[0]) != 36 or int(u.shape[2]) % 32 or os.environ.get("STROTSS_X3", "1") == "0" \
             or os.environ.get("STROTSS_X3_CONV", "1") == "0":           # default on, see csrc/winograd.hip x3_enabled
         return None
+    tiles128 = -(-(-(-h // 4) * -(-w // 4)) // 128) * -(-rows // 128) * 36
     fused_takes_it = (rows <= int(os.environ.get("STROTSS_WINO_FUSED_MAX_COUT", "256"))
-                      and rows < int(os.environ.get("STROTSS_X3_MIN_COUT", "256"))
+                      and (rows < int(os.environ.get("STROTSS_X3_MIN_COUT", "256")) or tiles128 < _x3_min_tiles())
                       and os.environ.get("STROTSS_WINO_FUSED", "1") != "0")
     if tiles < _x3_min_tiles() or fused_takes_it:
         return None

@@ -100,6 +100,9 @@ int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const fl
  * With it, the layers that run as one persistent kernel take their 36 products on the bf16 MFMA as well (same exact
  * split; STROTSS_WINO_FUSED_X3=0 selects the f32-MFMA kernel, which needs u_packed). */
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m);
+/* The Winograd weight transform itself: g_nk33 (n, k, 3, 3) = kernel as [out-row][in-col][r][q] -> u_pnk (P, n, k) with
+ * u_pnk[a * (tile_m + 2) + b] = (G g G^T)[a][b], P = (tile_m + 2)^2, computed in float64 and rounded once. */
+int strotss_conv3x3_winograd_weights(const float* g_nk33, int n, int k, int tile_m, float* u_pnk, void* stream);
 /* u_prk: (36, rows, k) -> x3 panels: per position p, element (r, c) split into bf16 planes h, m, l at
  * ((p * (k/32) + c/32) * 3 + plane) * rows * 32 + r * 32 + c % 32   (bf16 units).  k % 32 == 0. */
 size_t strotss_conv3x3_winograd_x3_bytes(int rows, int k);
@@ -175,6 +178,10 @@ int strotss_cosine_distance(const float* x, const float* rx, int nx, const float
  * strotss_row_inv_norm_x3 also writes the rows as "x3 panels" (3 * n * ld bf16; element (i, k), plane p at
  * ((k/32 * 3 + p) * n + i) * 32 + k%32); r may be NULL.  strotss_cosine_distance_x3 takes the panels of x and y;
  * x == y gives an exactly symmetric matrix.  The loss entry points below use this core unless STROTSS_X3=0. */
+/* C[i][j] = sqrt(max(|x_i|^2 + |y_j|^2 - 2 x_i.y_j, 1e-6) / d)   (nn/losses.py:18-24, l2_distance); x (nx, ld), y (ny, ld)
+ * row-major with columns >= d zero, ld % 32 == 0; C (nx, ldc); workspace: nx + ny floats. */
+int strotss_l2_distance(const float* x, int nx, const float* y, int ny, int d, int ld, float* C, int ldc,
+                        float* workspace, void* stream);
 int strotss_row_inv_norm_x3(const float* x, int n, int ld, float* r, void* panels, void* stream);
 int strotss_cosine_distance_x3(const void* x_panels, const float* rx, int nx, const void* y_panels, const float* ry,
                                int ny, int ld, float* C, int ldc, void* stream);

@@ -59,6 +59,16 @@ struct EpiCosDistX3 : EpiCosDist, X3NoPrefetch<EpiCosDistX3> {
     return 0.f;
   }
 };
+struct EpiL2Dist {  // C = sqrt(max(xs[i] + ys[j] - 2 acc, 1e-6) / D)      (losses.py:18-24)
+  static constexpr bool SYMM = false;
+  const float* xs; const float* ys; float* C; int ldc; int M, N; float inv_d;
+  __device__ __forceinline__ void set_batch(int) {}
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    if (r < M && c < N) C[(size_t)r * ldc + c] = sqrtf(fmaxf(xs[r] + ys[c] - 2.0f * v, 1e-06f) * inv_d);
+    return 0.f;
+  }
+  __device__ __forceinline__ void finish(float*, float) const {}
+};
 struct EpiScaleStore {  // C = alpha * acc   (batched: C += z * strideC)
   static constexpr bool SYMM = false;
   float* C; int ldc; int M, N; float alpha; long long strideC;
@@ -276,6 +286,12 @@ int launch(const float* A, int lda, int M, const float* B, int ldb, int N, int K
 int st_cosine_distance(const float* x, const float* rx, int nx, const float* y, const float* ry, int ny,
                        int ld, float* C, int ldc, hipStream_t s) {
   EpiCosDist e{rx, ry, C, ldc, nx, ny, (x == y && rx == ry && nx == ny) ? 1 : 0};
+  return launch_pipe<64, 64>(x, ld, nx, 0, y, ld, ny, 0, ld, 1, e, s);
+}
+
+int st_l2_distance(const float* x, const float* xs, int nx, const float* y, const float* ys, int ny, int ld, int d,
+                   float* C, int ldc, hipStream_t s) {
+  EpiL2Dist e{xs, ys, C, ldc, nx, ny, 1.0f / (float)d};
   return launch_pipe<64, 64>(x, ld, nx, 0, y, ld, ny, 0, ld, 1, e, s);
 }
 

@@ -24,6 +24,21 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restri
   if (lane == 0) r[row] = 1.0f / sqrtf(fmaxf(s, 1e-12f));
 }
 
+// s[i] = sum x[i,:]^2      (l2_distance, losses.py:19-20)
+__global__ __launch_bounds__(256) void row_sq_norm_kernel(const float* __restrict__ x, int n, int ld, float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* p = x + (size_t)row * ld;
+  float s = 0.f;
+  for (int k = lane * 4; k < ld; k += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + k);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
 // The same pass also writing the row as x3 panels (mfma_x3.h: three bf16 planes per value, K-blocked) for the
 // bf16x3 cost-matrix GEMM.  r may be NULL (norms already known).  ld % 32 == 0.
 // blockIdx.y = 1 selects a second matrix (x1, n1, r1, panels1): both feature matrices of a loss in one launch.
@@ -771,6 +786,19 @@ int strotss_cosine_distance(const float* x, const float* rx, int nx, const float
   ST_CHECK_ARG(x && rx && y && ry && C && nx > 0 && ny > 0 && ldc >= ny, STROTSS_EINVAL);
   ST_CHECK_ARG(ld % 32 == 0 && ld > 0, STROTSS_EALIGN);
   return st_cosine_distance(x, rx, nx, y, ry, ny, ld, C, ldc, (hipStream_t)stream);
+}
+
+int strotss_l2_distance(const float* x, int nx, const float* y, int ny, int d, int ld, float* C, int ldc,
+                        float* workspace, void* stream) {
+  ST_CHECK_ARG(x && y && C && workspace && nx > 0 && ny > 0 && d > 0 && d <= ld && ldc >= ny, STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  hipStream_t st = (hipStream_t)stream;
+  float* xs = workspace;
+  float* ys = workspace + nx;
+  hipLaunchKernelGGL(row_sq_norm_kernel, dim3(cdiv(nx, 4)), dim3(256), 0, st, x, nx, ld, xs);
+  hipLaunchKernelGGL(row_sq_norm_kernel, dim3(cdiv(ny, 4)), dim3(256), 0, st, y, ny, ld, ys);
+  LAUNCH_OK();
+  return st_l2_distance(x, xs, nx, y, ys, ny, ld, d, C, ldc, st);
 }
 
 int strotss_row_inv_norm_x3(const float* x, int n, int ld, float* r, void* panels, void* stream) {

@@ -381,7 +381,47 @@ int winograd_run(const float* in, int h, int w, int cin, const float* U, const f
 
 }  // namespace
 
+// U[a * (m + 2) + b][n][k] = (G g[n][k] G^T)[a][b] in float64, rounded once to float32 (one thread per (n, k) pair)
+__global__ __launch_bounds__(256) void winograd_weights_kernel(const float* __restrict__ g, long long nk, int tile_m,
+                                                              float* __restrict__ U) {
+  // Lavin & Gray: F(2x2,3x3) and F(4x4,3x3) (points 0, +-1, +-2, inf)
+  const double G2[4][3] = {{1.0, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1.0}};
+  const double G4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1.0}};
+  const int P = tile_m + 2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nk; e += (long long)gridDim.x * 256) {
+    double w[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) w[r][q] = (double)g[e * 9 + r * 3 + q];
+    for (int a = 0; a < P; ++a) {
+      double t[3];                                    // (G g)[a][q]
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        t[q] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t[q] += (tile_m == 2 ? G2[a][r] : G4[a][r]) * w[r][q];
+      }
+      for (int b = 0; b < P; ++b) {
+        double u = 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) u += t[q] * (tile_m == 2 ? G2[b][q] : G4[b][q]);
+        U[(size_t)(a * P + b) * nk + e] = (float)u;
+      }
+    }
+  }
+}
+
 extern "C" {
+
+int strotss_conv3x3_winograd_weights(const float* g_nk33, int n, int k, int tile_m, float* u_pnk, void* stream) {
+  ST_CHECK_ARG(g_nk33 && u_pnk && n > 0 && k > 0 && (tile_m == 2 || tile_m == 4), STROTSS_EINVAL);
+  const long long nk = (long long)n * k;
+  hipLaunchKernelGGL(winograd_weights_kernel, dim3((unsigned)min((long long)4096, (nk + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, g_nk33, nk, tile_m, u_pnk);
+  ST_LAUNCH_RET();
+}
 
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m) {
   if (tile_m == 4) {

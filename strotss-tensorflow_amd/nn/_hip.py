@@ -51,6 +51,7 @@ SIGNATURES = {
     "strotss_conv3x3_dgrad": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P]),
     "strotss_conv3x3_c3_dgrad": (_I, [_P, _I, _I, _I, _P, C.POINTER(_F), _P, _I, _P]),
     "strotss_conv3x3_winograd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "strotss_conv3x3_winograd_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "strotss_conv3x3_winograd_pack": (_I, [_P, _I, _I, _P, _P]),
     "strotss_conv3x3_winograd_x3_bytes": (_Z, [_I, _I]),
     "strotss_conv3x3_winograd_x3pack": (_I, [_P, _I, _I, _P, _P]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "strotss_hypercol_scatter": (_I, [C.POINTER(MapsT), _P, _I, _P, _I, _I, _I, _I, _P]),
     "strotss_row_inv_norm": (_I, [_P, _I, _I, _P, _P]),
     "strotss_cosine_distance": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _I, _P]),
+    "strotss_l2_distance": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
     "strotss_row_inv_norm_x3": (_I, [_P, _I, _I, _P, _P, _P]),
     "strotss_cosine_distance_x3": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _I, _P]),
     "strotss_selfsim_workspace_bytes": (_Z, [_I, _I]),

@@ -220,17 +220,17 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
     return out
 
 
-_WINO_G = {2: [[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]],
-           4: [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
-               [1 / 24, -1 / 12, 1 / 6], [0, 0, 1.0]]}
-
-
 def winograd_weights(g: torch.Tensor, tile_m: int = 2) -> torch.Tensor:
     """g: (N, K, 3, 3) kernel as [out-channel][in-channel][r][q] -> U (P, N, K) float32 with
-    U[a*(m+2)+b] = (G g G^T)[a, b], computed in float64 (P = 16 for tile_m = 2, 36 for tile_m = 4)."""
-    G = torch.tensor(_WINO_G[tile_m], dtype=torch.float64, device=g.device)
-    u = torch.einsum("ar,nkrq,bq->abnk", G, g.double(), G)
-    return u.reshape(G.shape[0] ** 2, g.shape[0], g.shape[1]).float().contiguous()
+    U[a*(m+2)+b] = (G g G^T)[a, b], computed in float64 on the device (P = 16 for tile_m = 2, 36 for tile_m = 4)."""
+    if not g.is_cuda:
+        g = g.to(torch.device("cuda", torch.cuda.current_device())) if torch.cuda.is_available() else g
+    g = g.float().contiguous()
+    require(g, "conv kernel")
+    n, k = int(g.shape[0]), int(g.shape[1])
+    u = torch.empty(((tile_m + 2) ** 2, n, k), dtype=torch.float32, device=g.device)
+    check(_hip.lib().strotss_conv3x3_winograd_weights(ptr(g), n, k, tile_m, ptr(u), stream_ptr()), "conv3x3_winograd_weights")
+    return u
 
 
 def maxpool2_fwd(x, out=None, code=None):
@@ -327,6 +327,16 @@ def cosine_distance(x, rx, nx, y, ry, ny) -> torch.Tensor:
     Cm = torch.empty((nx, ldc), dtype=torch.float32, device=x.device)
     check(_hip.lib().strotss_cosine_distance(ptr(x), ptr(rx), nx, ptr(y), ptr(ry), ny, x.shape[1], ptr(Cm),
                                              ldc, stream_ptr()), "cosine_distance")
+    return Cm
+
+
+def l2_distance(x, nx, y, ny, d) -> torch.Tensor:
+    """sqrt(max(|x_i|^2 + |y_j|^2 - 2 x_i.y_j, 1e-6) / d) on the f32 MFMA; x, y: zero-padded (rows, ld) buffers."""
+    ldc = pad32(ny)
+    Cm = torch.empty((nx, ldc), dtype=torch.float32, device=x.device)
+    ws = torch.empty(nx + ny, dtype=torch.float32, device=x.device)
+    check(_hip.lib().strotss_l2_distance(ptr(x), nx, ptr(y), ny, d, x.shape[1], ptr(Cm), ldc, ptr(ws), stream_ptr()),
+          "l2_distance")
     return Cm
 
 

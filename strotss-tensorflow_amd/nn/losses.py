@@ -39,12 +39,10 @@ def cosine_distance(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 
 def l2_distance(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """reference losses.py:18-24 (used by the reference with D = 3 only; device torch ops)."""
-    x_sq = (x ** 2).sum(dim=1).view(-1, 1)
-    y_sq = (y ** 2).sum(dim=1).view(1, -1)
-    matrix = x_sq + y_sq - 2. * (x @ y.T)
-    matrix = torch.clamp(matrix, min=1e-06) / x.shape[1]
-    return torch.sqrt(matrix)
+    """sqrt(max(|x|^2 + |y|^2 - 2 x y^T, 1e-6) / D)  (reference losses.py:18-24); forward only, on the f32 MFMA."""
+    bx, by = _buf(x), _buf(y)
+    nx, ny = x.shape[0], y.shape[0]
+    return _ops.l2_distance(bx, nx, by, ny, int(reshape_2d(x).shape[1]))[:, :ny]
 
 
 dist_metrics = {'cosine': cosine_distance, 'l2': l2_distance,

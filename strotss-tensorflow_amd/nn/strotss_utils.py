@@ -183,8 +183,9 @@ def fold_laplacian_pyramid(xs: Sequence[torch.Tensor]) -> torch.Tensor:
 
 def convert_rgb_to_yuv(x: torch.Tensor) -> torch.Tensor:
     """reference strotss_utils.py:166-167"""
-    m = torch.tensor(RGB2YUV, dtype=x.dtype, device=x.device)
-    return x[:, :3] @ m
+    # three axpys per output channel instead of a (N, 3) x (3, 3) library GEMM
+    r, g, b = x[:, 0:1], x[:, 1:2], x[:, 2:3]
+    return torch.cat([r * RGB2YUV[0][k] + g * RGB2YUV[1][k] + b * RGB2YUV[2][k] for k in range(3)], dim=1)
 
 
 def postprocess(final: torch.Tensor) -> torch.Tensor:

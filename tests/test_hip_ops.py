@@ -427,6 +427,28 @@ def test_loss_gradients_accumulate(ops):
     assert abs(lv[0] - lc) < 1e-5 and abs(lv[1] + lv[2] + lv[3] / 16.0 - ls) < 1e-5
 
 
+def test_l2_distance_and_winograd_weight_transform(ops):
+    """nn/losses.py:18-24 on the f32 MFMA (any width; the reference uses width 3), and the Winograd weight transform
+    G g G^T in float64 on the device -- the package holds no library GEMM (torch matmul / einsum) any more."""
+    from nn import losses as L
+    for n, m, d in ((70, 96, 3), (130, 64, 67), (33, 40, 259)):
+        x, y = _feat(n, d, 21), _feat(m, d, 22)
+        got = L.l2_distance(dev(x), dev(y)).cpu().numpy()
+        ref = R.l2_distance(x, y)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-5 * max(1.0, ref.max())
+    z = np.zeros((4, 5)); e = np.eye(5)[:4]
+    assert np.allclose(L.l2_distance(dev(e), dev(e)).cpu().numpy().diagonal(), (1e-6 / 5) ** 0.5, rtol=1e-5)   # the clamp
+    assert np.allclose(L.l2_distance(dev(z), dev(e)).cpu().numpy(), (1 / 5) ** 0.5, rtol=1e-6)
+    G = {2: np.array([[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]]),
+         4: np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                      [1 / 24, -1 / 12, 1 / 6], [0, 0, 1.0]])}
+    g = np.random.default_rng(5).standard_normal((48, 40, 3, 3)).astype(np.float32)
+    for m in (2, 4):
+        u = ops.winograd_weights(dev(g), m).cpu().numpy()
+        ref = np.einsum("ar,nkrq,bq->abnk", G[m], g.astype(np.float64), G[m]).reshape((m + 2) ** 2, 48, 40)
+        assert u.shape == ref.shape and np.abs(u - ref).max() <= 6e-8 * np.abs(ref).max()          # one f32 rounding
+
+
 # ------------------------------------------------------------------ optimiser / output
 def test_rmsprop_and_postprocess(ops):
     g = torch.Generator().manual_seed(0)

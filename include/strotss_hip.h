@@ -163,6 +163,16 @@ int strotss_hypercol_scatter(const strotss_maps_t* maps, const float* idx, int n
                              const float* gfeat, int ld, int relu_mask_from, int map_begin,
                              int map_end, void* stream);
 
+/* Deterministic form of the same adjoint (no float atomics; bitwise reproducible): strotss_hypercol_scatter_plan orders
+ * the (sample, tap) entries of EVERY map by destination pixel once per index set (n <= 1024) into `plan`
+ * (strotss_hypercol_scatter_plan_bytes(n_maps) bytes); strotss_hypercol_scatter_sorted then adds, per destination pixel
+ * of the maps [map_begin, map_end), the entries' contributions in plan order with one plain read-modify-write. */
+size_t strotss_hypercol_scatter_plan_bytes(int n_maps);
+int strotss_hypercol_scatter_plan(const strotss_maps_t* maps, const float* idx, int n, void* plan, size_t plan_bytes,
+                                  void* stream);
+int strotss_hypercol_scatter_sorted(const strotss_maps_t* maps, const void* plan, int n, const float* gfeat, int ld,
+                                    int relu_mask_from, int map_begin, int map_end, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Pairwise / moment losses  (nn/losses.py:12-80, run_strotss.py:21-40).
  * Every loss entry computes the loss value AND d(loss)/d(pred) scaled by `gscale`, added

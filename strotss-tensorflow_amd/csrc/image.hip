@@ -216,6 +216,113 @@ __global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m,
   }
 }
 
+// ---------------------------------------------------------------- deterministic adjoint (sorted scatter)
+// The atomic scatter above adds the taps of different samples into a shared pixel in whatever order the hardware
+// serves them: the gradient differs in its last bits from run to run.  The PLAN below orders every map's (sample, tap)
+// entries by destination pixel ONCE per index set (bitonic sort of <= 4096 keys in LDS, one workgroup per map); the
+// sorted scatter then gives each destination pixel to ONE workgroup, which sums its entries in plan order and adds the
+// sum with a plain read-modify-write: no atomics, bitwise reproducible.
+#define PLAN_E 4096                                  // entries per map: 4 taps x <= 1024 samples
+struct PlanView {
+  int* nseg; int* seg_start; int* pix; int* smp; float* w;
+  __host__ __device__ static size_t ints_per_map() { return 2 + (PLAN_E + 1) + 3 * (size_t)PLAN_E + 1; }
+  __host__ __device__ PlanView(void* base, int k) {
+    int* b = reinterpret_cast<int*>(base) + (size_t)k * ints_per_map();
+    nseg = b; seg_start = b + 2; pix = seg_start + PLAN_E + 1; smp = pix + PLAN_E; w = reinterpret_cast<float*>(smp + PLAN_E);
+  }
+};
+__global__ __launch_bounds__(1024) void scatter_plan_kernel(strotss_maps_t m, const float* __restrict__ idx, int n,
+                                                            void* __restrict__ plan) {
+  __shared__ unsigned long long key[PLAN_E];
+  __shared__ int wsum[16];
+  const int k = blockIdx.x, t = threadIdx.x;
+  const unsigned long long INVALID = ~0ull;
+  for (int e = t; e < PLAN_E; e += 1024) {
+    const int s = e >> 2, q = e & 3;
+    unsigned long long kk = INVALID;
+    if (s < n) {
+      const SampleTap tp = sample_tap(m, k, idx[2 * s], idx[2 * s + 1], 1);
+      const int ii = q == 0 ? tp.ia : q == 1 ? tp.ib : q == 2 ? tp.ic : tp.id;
+      const float ww = q == 0 ? tp.wa : q == 1 ? tp.wb : q == 2 ? tp.wc : tp.wd;
+      if (ww != 0.f) kk = ((unsigned long long)(unsigned)ii << 12) | (unsigned)e;
+    }
+    key[e] = kk;
+  }
+  __syncthreads();
+  for (int size = 2; size <= PLAN_E; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int p = t; p < PLAN_E / 2; p += 1024) {
+        const int lo = 2 * p - (p & (stride - 1));           // index of the pair's lower element
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = key[lo], b = key[hi];
+        if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  // heads of the runs of equal pixels -> segment starts (ordered: thread t owns positions 4t .. 4t+3)
+  PlanView pv(plan, k);
+  int head[4], cnt = 0, valid = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = 4 * t + i;
+    const unsigned long long a = key[p];
+    const bool ok = a != INVALID;
+    head[i] = ok && (p == 0 || (key[p - 1] >> 12) != (a >> 12));
+    cnt += head[i]; valid += ok;
+  }
+  int incl = cnt, vincl = valid;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64), v = __shfl_up(vincl, o, 64);
+    if ((t & 63) >= o) { incl += u; vincl += v; }
+  }
+  if ((t & 63) == 63) { wsum[t >> 6] = incl; }
+  __syncthreads();
+  int base = incl - cnt;
+  for (int wv = 0; wv < (t >> 6); ++wv) base += wsum[wv];
+  int total = 0;
+#pragma unroll
+  for (int wv = 0; wv < 16; ++wv) total += wsum[wv];
+  __syncthreads();
+  if ((t & 63) == 63) wsum[t >> 6] = vincl;
+  __syncthreads();
+  int nvalid = 0;
+#pragma unroll
+  for (int wv = 0; wv < 16; ++wv) nvalid += wsum[wv];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = 4 * t + i;
+    const unsigned long long a = key[p];
+    if (a == INVALID) continue;
+    const int e = (int)(a & 4095u), s = e >> 2, q = e & 3;
+    const SampleTap tp = sample_tap(m, k, idx[2 * s], idx[2 * s + 1], 1);
+    pv.pix[p] = (int)(a >> 12);
+    pv.smp[p] = s;
+    pv.w[p] = q == 0 ? tp.wa : q == 1 ? tp.wb : q == 2 ? tp.wc : tp.wd;
+    if (head[i]) pv.seg_start[base++] = p;
+  }
+  if (t == 0) { pv.nseg[0] = total; pv.seg_start[total] = nvalid; }
+}
+// one workgroup per destination pixel of map k (segment of the plan); off = first column of map k in gfeat
+__global__ __launch_bounds__(256) void scatter_sorted_kernel(strotss_maps_t m, int k, int off, const void* __restrict__ plan,
+                                                             const float* __restrict__ gfeat, int ld, int masked) {
+  PlanView pv(const_cast<void*>(plan), k);
+  const int sg = blockIdx.x;
+  if (sg >= pv.nseg[0]) return;
+  const int p0 = pv.seg_start[sg], p1 = pv.seg_start[sg + 1];
+  const int c = m.c[k];
+  const size_t pixel = (size_t)pv.pix[p0] * c;
+  const float* act = m.map[k];
+  float* dst = m.gmap[k];
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    if (masked && !(act[pixel + ch] > 0.f)) continue;
+    float acc = 0.f;
+    for (int p = p0; p < p1; ++p) acc += pv.w[p] * gfeat[(size_t)pv.smp[p] * ld + off + ch];
+    dst[pixel + ch] += acc;
+  }
+}
+
 // ---------------------------------------------------------------- optimiser
 __global__ __launch_bounds__(256) void rmsprop_kernel(strotss_tensors_t t, float lr, float rho, float eps) {
   const int k = blockIdx.y;
@@ -333,6 +440,39 @@ int strotss_hypercol_scatter(const strotss_maps_t* maps, const float* idx, int n
   ST_CHECK_ARG(ld >= d, STROTSS_EINVAL);
   hipLaunchKernelGGL(hypercol_scatter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, *maps, idx, gfeat,
                      ld, relu_mask_from, map_begin, map_end);
+  ST_LAUNCH_RET();
+}
+
+size_t strotss_hypercol_scatter_plan_bytes(int n_maps) {
+  return n_maps > 0 ? (size_t)n_maps * PlanView::ints_per_map() * sizeof(int) : 0;
+}
+
+int strotss_hypercol_scatter_plan(const strotss_maps_t* maps, const float* idx, int n, void* plan, size_t plan_bytes,
+                                  void* stream) {
+  ST_CHECK_ARG(maps_ok(maps) && idx && plan && n > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(4 * n <= PLAN_E, STROTSS_ERANGE);
+  ST_CHECK_ARG(plan_bytes >= strotss_hypercol_scatter_plan_bytes(maps->n_maps), STROTSS_EINVAL);
+  for (int k = 0; k < maps->n_maps; ++k) {
+    const long long px = (long long)(maps->rows[k] > 0 ? maps->rows[k] : maps->h[k]) * maps->w[k];
+    ST_CHECK_ARG(px < (1ll << 31), STROTSS_ERANGE);
+  }
+  hipLaunchKernelGGL(scatter_plan_kernel, dim3(maps->n_maps), dim3(1024), 0, (hipStream_t)stream, *maps, idx, n, plan);
+  ST_LAUNCH_RET();
+}
+
+int strotss_hypercol_scatter_sorted(const strotss_maps_t* maps, const void* plan, int n, const float* gfeat, int ld,
+                                    int relu_mask_from, int map_begin, int map_end, void* stream) {
+  ST_CHECK_ARG(maps_ok(maps) && plan && gfeat && n > 0 && 4 * n <= PLAN_E, STROTSS_EINVAL);
+  ST_CHECK_ARG(map_begin >= 0 && map_begin < map_end && map_end <= maps->n_maps, STROTSS_ERANGE);
+  int off = 0;
+  for (int k = 0; k < map_end; ++k) {
+    if (k >= map_begin) {
+      ST_CHECK_ARG(maps->gmap[k] != nullptr && off + maps->c[k] <= ld, STROTSS_EINVAL);
+      hipLaunchKernelGGL(scatter_sorted_kernel, dim3(4 * n), dim3(256), 0, (hipStream_t)stream, *maps, k, off, plan, gfeat,
+                         ld, k >= relu_mask_from ? 1 : 0);
+    }
+    off += maps->c[k];
+  }
   ST_LAUNCH_RET();
 }
 

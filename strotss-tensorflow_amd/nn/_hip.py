@@ -62,6 +62,9 @@ SIGNATURES = {
     "strotss_maxpool2_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "strotss_hypercol_gather": (_I, [C.POINTER(MapsT), _P, _I, _I, _P, _I, _P]),
     "strotss_hypercol_scatter": (_I, [C.POINTER(MapsT), _P, _I, _P, _I, _I, _I, _I, _P]),
+    "strotss_hypercol_scatter_plan_bytes": (_Z, [_I]),
+    "strotss_hypercol_scatter_plan": (_I, [C.POINTER(MapsT), _P, _I, _P, _Z, _P]),
+    "strotss_hypercol_scatter_sorted": (_I, [C.POINTER(MapsT), _P, _I, _P, _I, _I, _I, _I, _P]),
     "strotss_row_inv_norm": (_I, [_P, _I, _I, _P, _P]),
     "strotss_cosine_distance": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _I, _P]),
     "strotss_l2_distance": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),

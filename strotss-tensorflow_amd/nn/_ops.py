@@ -296,6 +296,28 @@ def hypercol_scatter(maps: Sequence[torch.Tensor], gmaps: Sequence[Optional[torc
                                               stream_ptr()), "hypercol_scatter")
 
 
+def hypercol_scatter_plan(maps_t, idx: torch.Tensor, plan: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Plan of the deterministic scatter for one index set (all maps of `maps_t`); returns the plan buffer."""
+    require(idx, "indices")
+    nb = _hip.lib().strotss_hypercol_scatter_plan_bytes(int(maps_t.n_maps))
+    if plan is None:
+        plan = torch.empty(nb, dtype=torch.uint8, device=idx.device)
+    check(_hip.lib().strotss_hypercol_scatter_plan(C.byref(maps_t), ptr(idx), idx.shape[0], plan.data_ptr(), plan.numel(),
+                                                   stream_ptr()), "hypercol_scatter_plan")
+    return plan
+
+
+def hypercol_scatter_sorted(maps_t, plan: torch.Tensor, n: int, gfeat: torch.Tensor, relu_mask_from: int = 1,
+                            map_begin: int = 0, map_end: Optional[int] = None):
+    """gmaps[k] += adjoint-gather of gfeat's columns of map k, k in [map_begin, map_end), in plan order (no atomics)."""
+    require(gfeat, "feature grads")
+    if map_end is None:
+        map_end = int(maps_t.n_maps)
+    check(_hip.lib().strotss_hypercol_scatter_sorted(C.byref(maps_t), plan.data_ptr(), n, ptr(gfeat), gfeat.shape[1],
+                                                     relu_mask_from, map_begin, map_end, stream_ptr()),
+          "hypercol_scatter_sorted")
+
+
 # ------------------------------------------------------------------ losses
 class _WsCache:
     """Grow-only workspace per (device, tag): the C ABI never allocates."""

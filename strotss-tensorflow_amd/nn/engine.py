@@ -61,7 +61,8 @@ class StepEngine:
     def __init__(self, params: VGGParams, content_feat: Sequence[torch.Tensor],
                  style_targets: Sequence[StyleTarget], stylized: torch.Tensor, alpha: float,
                  loss_denom: float, lr: float, sample_size: int = 1024, levels: int = 5,
-                 dist_group=None, rho: float = 0.99, eps: float = 1e-8, strips: Optional["parallel.StripPlan"] = None):
+                 dist_group=None, rho: float = 0.99, eps: float = 1e-8, strips: Optional["parallel.StripPlan"] = None,
+                 deterministic: Optional[bool] = None):
         dev = stylized.device
         self.params = params
         self.alpha, self.loss_denom, self.lr, self.rho, self.eps = float(alpha), float(loss_denom), float(lr), rho, eps
@@ -131,6 +132,14 @@ class StepEngine:
         if strips is not None:            # strips shard the image, not the regions: every rank runs region 0
             self.my_regions, self.world = [0], 1
         self._idx: List[Optional[torch.Tensor]] = [None] * self.R
+        # deterministic mode (STROTSS_DETERMINISTIC=1): the tap adjoint as a sorted scatter, one plan per region and step
+        # (no float atomics -> bitwise reproducible steps; the reference asks TF for the same: nn/rand.py:4-8)
+        import os
+        self.deterministic = (os.environ.get("STROTSS_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
+        self._plans = None
+        if self.deterministic:
+            nb = _hip.lib().strotss_hypercol_scatter_plan_bytes(len(self.pred_maps))
+            self._plans = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.R)]
         self.steps_done = 0
         self._graph = None
         self._graph_post = None           # sharded regions: the part of the step after the all-reduce
@@ -171,8 +180,12 @@ class StepEngine:
             idx, gp = self._idx[r], self.gp[r]
             if self.strips is not None:           # this rank's block of samples only
                 idx, gp = idx[self._o0:self._o1], gp[self._o0:self._o1]
-            _ops.hypercol_scatter(self.pred_maps, None, idx, gp, relu_mask_from=1, map_begin=k,
-                                  map_end=k + 1, maps_t=self._mt_pred)
+            if self.deterministic:
+                _ops.hypercol_scatter_sorted(self._mt_pred, self._plans[r], int(idx.shape[0]), gp, relu_mask_from=1,
+                                             map_begin=k, map_end=k + 1)
+            else:
+                _ops.hypercol_scatter(self.pred_maps, None, idx, gp, relu_mask_from=1, map_begin=k,
+                                      map_end=k + 1, maps_t=self._mt_pred)
 
     def forward_backward(self, indices: Sequence[torch.Tensor], strip_offsets: Optional[Sequence[int]] = None) -> None:
         """train_step (run_strotss.py:131-142 / 104-125): fills self.gvars and self.scalars.
@@ -203,6 +216,8 @@ class StepEngine:
             self._idx[r] = idx
             self._gather(self._mt_content, idx, self.cf[r])
             self._gather(self._mt_pred, idx, self.pf[r])
+            if self.deterministic:
+                _ops.hypercol_scatter_plan(self._mt_pred, idx, self._plans[r])
             self._losses(r, n)
         if self.my_regions:
             self.trunk.backward(self._scatter)
@@ -242,6 +257,8 @@ class StepEngine:
     def _strip_stage_b(self) -> None:
         """losses on the assembled features (replicated), backward of this rank's rows through its window."""
         self._losses(0, self._n)
+        if self.deterministic and self._o1 > self._o0:
+            _ops.hypercol_scatter_plan(self._mt_pred, self._idx[0][self._o0:self._o1], self._plans[0])
         if self._o1 > self._o0:
             self.trunk.backward(self._scatter)
         else:

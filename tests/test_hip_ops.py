@@ -257,6 +257,22 @@ def test_hypercol_gather_and_scatter(ops, hw):
     for k, (g_, leaf, m) in enumerate(zip(gm, leaves, maps)):
         ref_g = leaf.grad.numpy() * ((m.numpy() > 0) if k >= 1 else 1.0)
         assert np.abs(g_.cpu().numpy() - ref_g).max() < 1e-5 * max(1.0, np.abs(ref_g).max()), k
+    # the deterministic form: plan once, sorted scatter map range by map range -- same adjoint, and bitwise the same
+    # bits on every run (the coarse maps collect many samples per pixel: the atomic form's order is not fixed)
+    from nn import _hip
+    runs = []
+    for _ in range(2):
+        gs = [torch.zeros_like(m) for m in dmaps]
+        mt = _hip.make_maps(dmaps, ops.map_divisors([ops.hwc(m)[:2] for m in dmaps]), gs)
+        plan = ops.hypercol_scatter_plan(mt, dev(idx))
+        ops.hypercol_scatter_sorted(mt, plan, len(idx), gbuf, relu_mask_from=1, map_begin=3, map_end=len(maps))
+        ops.hypercol_scatter_sorted(mt, plan, len(idx), gbuf, relu_mask_from=1, map_begin=0, map_end=3)
+        torch.cuda.synchronize()
+        runs.append(gs)
+    for k, (a, b, leaf, m) in enumerate(zip(runs[0], runs[1], leaves, maps)):
+        ref_g = leaf.grad.numpy() * ((m.numpy() > 0) if k >= 1 else 1.0)
+        assert torch.equal(a, b), k
+        assert np.abs(a.cpu().numpy() - ref_g).max() < 1e-5 * max(1.0, np.abs(ref_g).max()), k
 
 
 # ------------------------------------------------------------------ losses

@@ -44,6 +44,23 @@ def img(h, w, seed):
     return torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1).contiguous()
 
 
+def jpeg_fixture():
+    """Decoded pixels of the reference's two images as the product's loader sees them (PIL: libjpeg ISLOW DCT + fancy
+    upsampling, the algorithm tf.image.decode_jpeg(dct_method='INTEGER_ACCURATE') names, nn/utils.py:44-57 of the
+    reference): shape, SHA-256 of the uint8 bytes, channel sums and a 6 x 6 crop.  Pins the host image pipeline."""
+    import hashlib
+    from PIL import Image
+    out = {}
+    for name in ("content_im", "style_im"):
+        with Image.open(os.path.join(HERE, name + ".jpg")) as im:
+            px = np.array(im.convert("RGB"))
+        out[name + "_shape"] = np.array(px.shape)
+        out[name + "_sha256"] = np.frombuffer(hashlib.sha256(px.tobytes()).digest(), dtype=np.uint8)
+        out[name + "_sums"] = px.reshape(-1, 3).astype(np.int64).sum(0)
+        out[name + "_crop"] = px[100:106, 200:206].copy()
+    np.savez_compressed(os.path.join(HERE, "jpeg_decode.npz"), **out)
+
+
 def trace_fixture():
     """64-px single-scale trace: seeded synthetic VGG16 (seed 0), injected indices, 4 steps."""
     h = w = 64
@@ -96,11 +113,16 @@ def image_fixture():
     np.savez_compressed(os.path.join(HERE, "image_21x32.npz"), **out)
 
 
+if __name__ == "__main__" and "--jpeg-only" in sys.argv:
+    jpeg_fixture()
+    sys.exit(0)
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     losses_fixture()
     image_fixture()
     trace_fixture()
+    jpeg_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

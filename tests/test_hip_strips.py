@@ -90,6 +90,63 @@ def test_strip_sharded_step_equals_unsharded(cfg):
     assert rel < 1.5e-2, rel                              # second step: same effect on top of the first (measured <= 9.4e-3)
 
 
+def test_strip_sharded_step_matches_the_float64_oracle():
+    """Sharded HIP step against the ORACLE (not against the unsharded HIP step): a 512 x 64 image over two emulated
+    ranks with the full 128-row margin; losses and the six variable gradients at the single-GPU tolerances of
+    tests/test_hip_engine.py (losses 5e-5, gradients 2e-2 relative L2: sign flips of the L1 / hard-min terms)."""
+    from oracle import strotss_oracle as O
+    from nn import _ops, engine, parallel
+    from nn.model import VGGParams, synthetic_weights
+    h, w, world, n_samples = 512, 64, 2, 256
+    weights = synthetic_weights('16', 0)
+    content, style = _img(h, w, 1), _img(h // 2, w, 2)
+    rng = np.random.default_rng(0)
+    alpha = 4.0
+    denom = 2.0 + alpha + 1.0 / alpha
+    # ---- oracle (float64)
+    vgg = O.VGG(weights, dtype=torch.float64)
+    c64, s64 = content.double(), style.double()
+    with torch.no_grad():
+        cf = [c64] + vgg(c64)
+        sf = [s64] + vgg(s64)
+    s_idx = O.make_indices(h // 2, w, False, n_samples, rng)
+    idx = O.make_indices(h, w, True, n_samples, rng)
+    with torch.no_grad():
+        ss = O.sample_features(sf, s_idx, False)
+    init = O.make_laplacian(c64) + s64.mean(dim=(1, 2), keepdim=True)
+    variables = [v.clone().requires_grad_(True) for v in O.make_laplacian_pyramid(init)]
+    # ---- HIP, two emulated ranks
+    params = VGGParams(weights, '16', None, DEV)
+    cfeat = engine.extract_features(params, content.to(DEV))
+    sfeat = engine.extract_features(params, style.to(DEV))
+    target = engine.StyleTarget.build(_ops.hypercol_gather(sfeat, torch.from_numpy(s_idx).to(DEV), False), len(s_idx), 2179)
+    plans = [parallel.strip_plan(h, world, r) for r in range(world)]
+    assert all(p is not None for p in plans)
+    engs = [engine.StepEngine(params, cfeat, [target], init.float().to(DEV), alpha, denom, 2e-3, sample_size=n_samples,
+                              strips=p) for p in plans]
+    idx_sorted, offs = parallel.sort_indices_by_strip(idx, plans[0])
+    ref = O.train_step(variables, vgg, cf, ss, idx_sorted, alpha, denom)      # the losses are order-invariant
+    ti = torch.from_numpy(idx_sorted).to(DEV)
+    for e in engs:
+        e._strip_stage_a(ti, offs)
+    pf = sum(e.pf[0] for e in engs)                       # the feature all-reduce, by hand
+    assert float((pf[:n_samples, :2179].cpu().double() - ref["p_feat"]).abs().max()) < 5e-5 * float(ref["p_feat"].abs().max())
+    for e in engs:
+        e.pf[0].copy_(pf)
+        e._strip_stage_b()
+    g = sum(e.gimg_full for e in engs)                    # the pixel-gradient all-reduce, by hand
+    for e in engs:
+        e.gimg_full.copy_(g)
+        e._fold_adjoint()
+    torch.cuda.synchronize()
+    got = engs[0].losses()
+    for k in ("loss", "loss_c", "loss_s"):
+        assert abs(got[k] - float(ref[k])) < 5e-5 * max(1.0, abs(float(ref[k]))), (k, got[k], float(ref[k]))
+    for k, (a, b) in enumerate(zip(engs[0].gvars, ref["grads"])):
+        rel = float((a.cpu().double() - b).norm() / b.norm())
+        assert rel < 2e-2, (k, rel)
+
+
 def test_strip_margin_must_cover_the_receptive_field():
     """With a margin far below the receptive-field radius the halo is wrong and the test above would fail:
     guards against the margin constant being silently reduced."""

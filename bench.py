@@ -279,13 +279,15 @@ def pmc_traffic(path=TRAFFIC_CSV):
     import csv
     if not os.path.exists(path):
         return None
-    fam = ("winograd", "gemm_kc_pipe_kernel", "conv3x3_mfma_pipe_kernel")     # winograd43_fused_kernel: one kernel = one launch
+    fam = ("winograd", "gemm_kc_pipe_kernel", "gemm_x3_kernel", "conv3x3_mfma_pipe_kernel")   # fused kernel: one launch
     total, launches = 0.0, 0
     with open(path) as f:
         rd = csv.reader(f)
         next(rd)
         for name, _grid, n, r_mb, w_mb in rd:
-            if not name.startswith(fam) or ("gemm_kc" in name and "EpiScaleStore" not in name):
+            if not name.startswith(fam) or (name.startswith("gemm_") and "EpiScaleStore" not in name):
+                continue                                # GEMMs of the loss section carry other epilogues
+            if r_mb == "nan" or w_mb == "nan":
                 continue
             total += int(n) * (float(r_mb) + float(w_mb)) * 1e6
             if not name.startswith("winograd") or name.startswith("winograd43_fused"):

@@ -320,7 +320,10 @@ def hypercol_scatter_sorted(maps_t, plan: torch.Tensor, n: int, gfeat: torch.Ten
 
 # ------------------------------------------------------------------ losses
 class _WsCache:
-    """Grow-only workspace per (device, tag): the C ABI never allocates."""
+    """Grow-only workspace per (device, tag): the C ABI never allocates.  Growth REALLOCATES, which a captured hipGraph
+    must never see (the graph holds the old pointer): StepEngine.capture_graph therefore runs one full eager step on a
+    side stream first, so every workspace of the step has its final size before capture; sizes depend on the engine's
+    shapes only, never on the data."""
 
     def __init__(self):
         self.bufs = {}

@@ -130,7 +130,10 @@ def time_kernel_families(eng, idx, steps=7):
     graph): one untimed eager step first, then `steps` timed ones; per call site (family, ordinal of the call inside the
     step) the MEDIAN over the steps is kept, so that a host hiccup between an event and its launch (in eager mode the GPU
     waits for the host on the small kernels; a Python GC pause there once put 43 ms on one scatter call) cannot leak into
-    a family's figure.  The cyclic GC is off during the pass for the same reason."""
+    a family's figure.  The cyclic GC is off during the pass for the same reason.  (The pass that once reported a
+    14.5 ms scatter -- BENCH_r01.json -- dropped the step's hipGraph right before its first eager step: the graph's
+    destruction, hipGraphExecDestroy + the release of its capture pool, ran into that step.  The graph now stays
+    alive until the pass is over.)"""
     import gc
     from nn import _ops, engine
     rec, step_no = [], [0]
@@ -139,6 +142,10 @@ def time_kernel_families(eng, idx, steps=7):
     def timed_call(name, orig):
         def timed(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # a ~40 us spin on the stream first: the host enqueues e0, the launches and e1 while the GPU is still busy, so
+            # the interval holds the kernels' own time and not the host's launch latency (without it a 6 us resize
+            # launch read 25 us: the idle GPU waiting for the next eager submission)
+            torch.cuda._sleep(80000)
             e0.record()
             r = orig(*a, **k)
             e1.record()

@@ -66,15 +66,20 @@ int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, c
                            int cout, const float* mean3, const float* std3, float* out, void* stream);
 /* Generic layer, cin % 32 == 0, cout % 64 == 0:
  *   out(h,w,cout) = relu(conv3x3(in(h,w,cin)) + bias);  w_tok: (9, cout, cin), tap = dy*3+dx. */
+/* workspace (may be NULL; strotss_conv3x3_workspace_bytes(h, w, cin, cout) bytes, 0 for big maps): with it, layers of at
+ * most 64 output tiles of 64 x 64 (the 4x4 ... 32x32 pixel maps of the small scales) split K over up to 256 workgroups
+ * and a finish kernel adds the partial tiles in a fixed order (same result class, bitwise reproducible). */
+size_t strotss_conv3x3_workspace_bytes(int h, int w, int cin, int cout);
 int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float* w_tok,
-                             const float* bias, int cout, float* out, void* stream);
+                             const float* bias, int cout, float* out, void* workspace, size_t workspace_bytes,
+                             void* stream);
 /* Data gradient of the generic layer (no weight gradient: the net is frozen, model.py:45):
  *   gin(h,w,cin) = conv3x3^T(gout(h,w,cout)) [* (act_in > 0) if act_in != NULL]
  *   gout must already carry the ReLU mask of ITS layer.  w_tik: (9, cin, cout) spatially
  *   flipped kernel, tap' = (2-dy)*3+(2-dx).  act_in = the layer's (post-ReLU) input or NULL
  *   when the input came from a max-pool. */
 int strotss_conv3x3_dgrad(const float* gout, int h, int w, int cout, const float* w_tik, int cin,
-                          const float* act_in, float* gin, void* stream);
+                          const float* act_in, float* gin, void* workspace, size_t workspace_bytes, void* stream);
 /* Data gradient of the first layer down to the pixels, preprocess adjoint fused:
  *   gimg(h,w,3) (+)= conv3x3^T(gout(h,w,cout)) / std.   w_tic: (9, 3, cout) flipped kernel.
  *   accumulate != 0 adds to gimg (the hypercolumn scatter of map 0 lands there first).

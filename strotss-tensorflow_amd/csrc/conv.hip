@@ -122,6 +122,11 @@ struct ConvALoader {   // A(pixel, k) = in[pixel + tap offset][ci]; out-of-image
     }
     off = (-W_ - 1) * Cin_;
   }
+  __device__ __forceinline__ void seek(int step) {          // start at K-step `step` = (tap, 32-channel chunk)
+    const int kch = Cin >> 5;
+    tap = step / kch; ci0 = (step - tap * kch) << 5;
+    off = ((tap / 3 - 1) * W + (tap - (tap / 3) * 3 - 1)) * Cin + ci0;
+  }
   __device__ __forceinline__ void issue(int i, int slot) {
     const bool ok = (tapmask[i] >> tap) & 1u;
     r[slot][i] = *reinterpret_cast<const f32x4*>(in + (ok ? base[i] + off : base[i]));
@@ -150,6 +155,11 @@ struct ConvBLoader {   // B(co, k) = wt[tap][co][ci]
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 #pragma unroll
     for (int i = 0; i < Cfg::NB; ++i) base[i] = (n0 + r0 + Cfg::RPP * i) * Cin_ + c4 * 4;
+  }
+  __device__ __forceinline__ void seek(int step) {
+    const int kch = Cin >> 5;
+    tap = step / kch; ci0 = (step - tap * kch) << 5;
+    off = tap * CoutCin + ci0;
   }
   __device__ __forceinline__ void issue(int i, int slot) { r[slot][i] = *reinterpret_cast<const f32x4*>(wt + base[i] + off); }
   __device__ __forceinline__ f32x4 value(int i, int slot) const { return r[slot][i]; }
@@ -213,6 +223,75 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_pipe_kernel(const float*
   }
 }
 
+// ---- split-K form for SMALL maps (the 64-256 px scales: 4x4 ... 32x32 pixel maps).  There the whole layer is a few
+// 64 x 64 output tiles and the three-kernel Winograd form is three dependent, latency-bound launches of 5-9 us each;
+// here `nsplit` workgroups per tile take consecutive ranges of the 9 * Cin / 32 K-steps (a 512 -> 512 layer on 4 x 4
+// pixels: 8 tiles x 32 splits = 256 workgroups, each streams 37 KB of weights), write their partial tiles, and the
+// finish kernel adds them in split order (fixed: bitwise reproducible) with bias / ReLU / mask.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_splitk_kernel(const float* __restrict__ in, int H, int W, int Cin,
+                                                                      const float* __restrict__ wt, int Cout, int nsplit,
+                                                                      float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+  const int HW = H * W;
+  const unsigned gx = Cout / Cfg::BN, gy = (HW + Cfg::BM - 1) / Cfg::BM, ntile = gx * gy;
+  const unsigned id = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned sp = id / ntile, tile = id - sp * ntile;       // split slowest: an XCD's run shares one K range
+  const int m0 = (tile / gx) * Cfg::BM, n0 = (tile % gx) * Cfg::BN;
+  const int S = 9 * (Cin >> 5);
+  const int s0 = (int)((long long)S * sp / nsplit), s1 = (int)((long long)S * (sp + 1) / nsplit);
+  ConvALoader<Cfg> la(in, H, W, Cin, m0);
+  ConvBLoader<Cfg> lb(wt, Cin, Cout, n0);
+  la.seek(s0); lb.seek(s0);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  pipe_mainloop<Cfg>(lds, s1 - s0, la, lb, acc);
+  PipeAccMap<Cfg> map;
+  float* P = part + (size_t)sp * HW * Cout;
+#pragma unroll
+  for (int in_ = 0; in_ < Cfg::TN; ++in_)
+#pragma unroll
+    for (int im = 0; im < Cfg::TM; ++im)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int p = m0 + map.row(im, reg);
+        if (p < HW) P[(size_t)p * Cout + n0 + map.colof(in_)] = acc[im][in_][reg];
+      }
+}
+// out = epilogue(sum_s part[s]): + bias, ReLU (forward) or * (mask > 0) (data-gradient); 4 channels per thread
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const f32x4* __restrict__ part, int nsplit, size_t total4,
+                                                                 int cout4, const f32x4* __restrict__ bias,
+                                                                 const f32x4* __restrict__ mask, int relu,
+                                                                 f32x4* __restrict__ out) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
+    f32x4 v = part[e];
+    for (int sp = 1; sp < nsplit; ++sp) v = v + part[(size_t)sp * total4 + e];
+    if (bias) v = v + bias[e % cout4];
+    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (mask) {
+      const f32x4 m = mask[e];
+      v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f; v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
+    }
+    out[e] = v;
+  }
+}
+// number of K splits for a (h, w, cin, cout) layer, 0 = one-pass kernel: only when the layer is at most 128 tiles of 64 x 64
+static int conv_splits(int H, int W, int Cin, int Cout) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("STROTSS_CONV_SPLITK"); on = e ? atoi(e) : 1; }
+  const long tiles = (long)cdiv((int64_t)H * W, 64) * (Cout / 64);
+  const int S = 9 * (Cin >> 5);
+  if (!on || tiles > 128) return 0;
+  int n = (int)(256 / tiles);
+  if (n > S / 2) n = S / 2;                          // at least two K-steps per workgroup
+  return n >= 2 ? n : 0;
+}
+
 static int conv_variant() {
   static int v = -1;
   if (v < 0) {
@@ -258,8 +337,20 @@ int launch_conv(const float* in, int H, int W, int Cin, const float* wt, const f
 }
 
 int conv_dispatch(const float* in, int H, int W, int Cin, const float* wt, const float* bias, int Cout,
-                  const float* mask, float* out, int relu, hipStream_t s) {
+                  const float* mask, float* out, int relu, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0) {
   const int64_t M = (int64_t)H * W;
+  const int nsplit = conv_splits(H, W, Cin, Cout);
+  if (nsplit && workspace && workspace_bytes >= (size_t)nsplit * M * Cout * sizeof(float)) {
+    using Cfg = PipeCfg<64, 64, 2, 2>;
+    const unsigned tiles = (unsigned)(cdiv(M, 64) * (Cout / 64));
+    hipLaunchKernelGGL((conv3x3_mfma_splitk_kernel<Cfg>), dim3(tiles * nsplit), dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, Cout,
+                       nsplit, (float*)workspace);
+    const size_t total4 = (size_t)M * Cout / 4;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)min((size_t)2048, (total4 + 255) / 256)), dim3(256), 0, s,
+                       (const f32x4*)workspace, nsplit, total4, Cout / 4, (const f32x4*)bias, (const f32x4*)mask, relu,
+                       (f32x4*)out);
+    ST_LAUNCH_RET();
+  }
   if (Cout % 128 == 0 && cdiv(M, 128) * (Cout / 128) >= 512)
     return launch_conv<128, 128>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s);
   if (cdiv(M, 128) * (Cout / 64) >= 512)
@@ -617,19 +708,24 @@ int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, c
   ST_LAUNCH_RET();
 }
 
+size_t strotss_conv3x3_workspace_bytes(int h, int w, int cin, int cout) {
+  if (h <= 0 || w <= 0 || cin <= 0 || cin % 32 || cout <= 0 || cout % 64) return 0;
+  return (size_t)conv_splits(h, w, cin, cout) * h * w * cout * sizeof(float);
+}
+
 int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float* w_tok, const float* bias,
-                             int cout, float* out, void* stream) {
+                             int cout, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(in && w_tok && bias && out && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, STROTSS_EALIGN);
-  return conv_dispatch(in, h, w, cin, w_tok, bias, cout, nullptr, out, 1, (hipStream_t)stream);
+  return conv_dispatch(in, h, w, cin, w_tok, bias, cout, nullptr, out, 1, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 int strotss_conv3x3_dgrad(const float* gout, int h, int w, int cout, const float* w_tik, int cin,
-                          const float* act_in, float* gin, void* stream) {
+                          const float* act_in, float* gin, void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(gout && w_tik && gin && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
   // the transposed convolution is a convolution with K = cout and N = cin
-  return conv_dispatch(gout, h, w, cout, w_tik, nullptr, cin, act_in, gin, 0, (hipStream_t)stream);
+  return conv_dispatch(gout, h, w, cout, w_tik, nullptr, cin, act_in, gin, 0, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const float* w_tic,

@@ -72,7 +72,9 @@ def conv3x3_relu_fwd(x, w_tok, bias, out=None):
     cout = bias.numel()
     if out is None:
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
-    check(_hip.lib().strotss_conv3x3_relu_fwd(ptr(x), h, w, cin, ptr(w_tok), ptr(bias), cout, ptr(out),
+    nb = _hip.lib().strotss_conv3x3_workspace_bytes(h, w, cin, cout)
+    ws = workspaces.get("conv_splitk", nb, x.device) if nb else None
+    check(_hip.lib().strotss_conv3x3_relu_fwd(ptr(x), h, w, cin, ptr(w_tok), ptr(bias), cout, ptr(out), ptr(ws), nb,
                                               stream_ptr()), "conv3x3_relu_fwd")
     return out
 
@@ -81,7 +83,9 @@ def conv3x3_dgrad(gout, w_tik, cin, act_in=None, out=None):
     require(gout, "conv grad"); h, w, cout = hwc(gout)
     if out is None:
         out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
-    check(_hip.lib().strotss_conv3x3_dgrad(ptr(gout), h, w, cout, ptr(w_tik), cin, ptr(act_in), ptr(out),
+    nb = _hip.lib().strotss_conv3x3_workspace_bytes(h, w, cout, cin)
+    ws = workspaces.get("conv_splitk", nb, gout.device) if nb else None
+    check(_hip.lib().strotss_conv3x3_dgrad(ptr(gout), h, w, cout, ptr(w_tik), cin, ptr(act_in), ptr(out), ptr(ws), nb,
                                            stream_ptr()), "conv3x3_dgrad")
     return out
 

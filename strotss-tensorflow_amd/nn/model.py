@@ -88,7 +88,19 @@ def use_winograd(cin: int, cout: int) -> bool:
     return cin % 32 == 0 and cout % 64 == 0
 
 
-def winograd_tile(h: int, w: int, cin: int = 128) -> int:
+def direct_splitk(h: int, w: int, cin: int, cout: int) -> bool:
+    """Small maps: the direct kernel with K split over up to 256 workgroups + a fixed-order finish kernel (csrc/conv.hip)
+    instead of the three dependent, latency-bound launches of the Winograd form.  Measured by scale (bench.py --scale,
+    ms/step with / without): 64 px 0.87 / 0.97, 128 px 0.96 / 1.07, 256 px 1.27 / 1.28; beyond these borders the
+    direct form's 4x MACs cost more than the launches save (256 px with every layer up to 256 tiles: 1.40).
+    A layer takes it with at most STROTSS_DIRECT_MAX_TILES (64) output tiles of 64 x 64, or at most 4x that many when it
+    has at most 128 channels on both sides (short K); 0 switches it off."""
+    tiles = -(-(h * w) // 64) * (cout // 64)
+    mt = int(os.environ.get("STROTSS_DIRECT_MAX_TILES", "64"))
+    return 0 < tiles <= mt or (max(cin, cout) <= 128 and 0 < tiles <= 4 * mt)
+
+
+def winograd_tile(h: int, w: int, cin: int = 128, cout: int = 0) -> int:
     """0 = direct kernel, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for a layer with `cin` input channels at (h, w).
     Measured on MI355X (tools/conv_bench.py): F(4x4,3x3) -- 2.25 MACs per output, transform tensors 2.25x the
     activations -- wins from 32x32 pixels up for every channel count (1.2x at 64->64 ... 2.9x at 512->512 over
@@ -99,6 +111,8 @@ def winograd_tile(h: int, w: int, cin: int = 128) -> int:
     mode = os.environ.get("STROTSS_WINOGRAD_TILE", "auto")
     if mode in ("2", "4"):
         return int(mode) if cin >= 128 else 0
+    if cout and direct_splitk(h, w, cin, cout):
+        return 0
     if h * w >= 1024:
         return 4
     return 2 if cin >= 128 else 0
@@ -205,7 +219,7 @@ class VGGTrunk:
         self.taps = params.tap_layer_indices
         self.with_grad = with_grad
         # Winograd tile per layer for this image size
-        self.wtile = [winograd_tile(int(a.shape[1]), int(a.shape[2]), L["cin"]) if "u_fwd" in L else 0
+        self.wtile = [winograd_tile(int(a.shape[1]), int(a.shape[2]), L["cin"], L["cout"]) if "u_fwd" in L else 0
                       for L, a in zip(params.layers, self.acts)]
         if with_grad:
             # argmax codes of the pools (1 byte per pooled element): the backward pass reads them, not the activations

@@ -118,6 +118,19 @@ def winograd_tile(h: int, w: int, cin: int = 128, cout: int = 0) -> int:
     return 2 if cin >= 128 else 0
 
 
+class _LazyWinograd:
+    """u[m] = Winograd-domain weights (P, rows, k) of one layer and direction for tile size m, made on first use."""
+
+    def __init__(self, w_hwio: torch.Tensor, forward: bool):
+        self.w, self.forward, self.u = w_hwio, forward, {}
+
+    def __getitem__(self, m: int) -> torch.Tensor:
+        if m not in self.u:
+            g = self.w.permute(3, 2, 0, 1) if self.forward else self.w.flip(0, 1).permute(2, 3, 0, 1)
+            self.u[m] = _ops.winograd_weights(g, m)
+        return self.u[m]
+
+
 class VGGParams:
     """Frozen weights on the device in the layouts the kernels want (built once)."""
 
@@ -168,12 +181,12 @@ class VGGParams:
                 L["w_bwd"] = w.flip(0, 1).reshape(9, cin, cout).contiguous().to(device)           # (9,cin,cout)
                 if use_winograd(cin, cout):
                     # forward: g[co][ci][r][q] = W[r,q,ci,co]; dgrad: g'[ci][co][r][q] = W[2-r,2-q,ci,co].
-                    # The float64 transform G g G^T runs where the weights will live (one-time setup, not the hot
-                    # path: 0.8 s of host einsum for the 12 layers x 2 directions x 2 tilings otherwise).
-                    wd = w.to(device)
-                    L["u_fwd"] = {m: _ops.winograd_weights(wd.permute(3, 2, 0, 1), m).to(device) for m in (2, 4)}
-                    L["u_bwd"] = {m: _ops.winograd_weights(wd.flip(0, 1).permute(2, 3, 0, 1), m).to(device)
-                                  for m in (2, 4)}
+                    # The float64 transform G g G^T runs on the device, and only for the (direction, tiling) pairs a
+                    # trunk actually asks for: all four for all 12 layers are 104x the weights = 6 GB and a third of
+                    # the model's build time, and F(2x2,3x3) is hardly ever chosen since the small maps take the
+                    # direct split-K kernel.
+                    L["u_fwd"] = _LazyWinograd(w, forward=True)
+                    L["u_bwd"] = _LazyWinograd(w, forward=False)
             self.layers.append(L)
         self.device = device
 

@@ -78,8 +78,12 @@ int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float
  *   gout must already carry the ReLU mask of ITS layer.  w_tik: (9, cin, cout) spatially
  *   flipped kernel, tap' = (2-dy)*3+(2-dx).  act_in = the layer's (post-ReLU) input or NULL
  *   when the input came from a max-pool. */
+/* accumulate != 0: gin += the (masked) data gradient instead of being overwritten -- the buffer then already holds the
+ * hypercolumn taps' contributions of this layer (scattered in one launch for all maps before the backward pass);
+ * supported by the split-K form only (strotss_conv3x3_workspace_bytes(h, w, cout, cin) > 0), STROTSS_EINVAL otherwise. */
 int strotss_conv3x3_dgrad(const float* gout, int h, int w, int cout, const float* w_tik, int cin,
-                          const float* act_in, float* gin, void* workspace, size_t workspace_bytes, void* stream);
+                          const float* act_in, float* gin, int accumulate, void* workspace, size_t workspace_bytes,
+                          void* stream);
 /* Data gradient of the first layer down to the pixels, preprocess adjoint fused:
  *   gimg(h,w,3) (+)= conv3x3^T(gout(h,w,cout)) / std.   w_tic: (9, 3, cout) flipped kernel.
  *   accumulate != 0 adds to gimg (the hypercolumn scatter of map 0 lands there first).
@@ -137,9 +141,9 @@ int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, co
 int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, void* stream);
 /* gin(h,w,c) = route gout(h/2,w/2,c) to the first max of each window, times (act > 0) where
  * act(h,w,c) is the pooled layer's input (post-ReLU).  Overwrites gin.  With code != NULL (from the forward pass)
- * act is not read (may be NULL): 1 byte instead of 16 per pooled element. */
+ * act is not read (may be NULL): 1 byte instead of 16 per pooled element.  accumulate != 0: gin += instead of gin =. */
 int strotss_maxpool2_bwd(const float* act, int h, int w, int c, const float* gout, float* gin,
-                         const unsigned char* code, void* stream);
+                         const unsigned char* code, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sampling._sample: hypercolumn gather  (nn/strotss_utils.py:25-81) and its adjoint

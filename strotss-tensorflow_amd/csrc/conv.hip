@@ -267,7 +267,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_splitk_kernel(const floa
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const f32x4* __restrict__ part, int nsplit, size_t total4,
                                                                  int cout4, const f32x4* __restrict__ bias,
                                                                  const f32x4* __restrict__ mask, int relu,
-                                                                 f32x4* __restrict__ out) {
+                                                                 f32x4* __restrict__ out, int accumulate) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
     f32x4 v = part[e];
     for (int sp = 1; sp < nsplit; ++sp) v = v + part[(size_t)sp * total4 + e];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const f32x4* __
       const f32x4 m = mask[e];
       v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f; v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
     }
-    out[e] = v;
+    out[e] = accumulate ? out[e] + v : v;
   }
 }
 // number of K splits for a (h, w, cin, cout) layer, 0 = one-pass kernel: only when the layer is at most 128 tiles of 64 x 64
@@ -337,7 +337,8 @@ int launch_conv(const float* in, int H, int W, int Cin, const float* wt, const f
 }
 
 int conv_dispatch(const float* in, int H, int W, int Cin, const float* wt, const float* bias, int Cout,
-                  const float* mask, float* out, int relu, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0) {
+                  const float* mask, float* out, int relu, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0,
+                  int accumulate = 0) {
   const int64_t M = (int64_t)H * W;
   const int nsplit = conv_splits(H, W, Cin, Cout);
   if (nsplit && workspace && workspace_bytes >= (size_t)nsplit * M * Cout * sizeof(float)) {
@@ -348,9 +349,10 @@ int conv_dispatch(const float* in, int H, int W, int Cin, const float* wt, const
     const size_t total4 = (size_t)M * Cout / 4;
     hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)min((size_t)2048, (total4 + 255) / 256)), dim3(256), 0, s,
                        (const f32x4*)workspace, nsplit, total4, Cout / 4, (const f32x4*)bias, (const f32x4*)mask, relu,
-                       (f32x4*)out);
+                       (f32x4*)out, accumulate);
     ST_LAUNCH_RET();
   }
+  if (accumulate) return STROTSS_EINVAL;              // only the split-K form adds to its output
   if (Cout % 128 == 0 && cdiv(M, 128) * (Cout / 128) >= 512)
     return launch_conv<128, 128>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s);
   if (cdiv(M, 128) * (Cout / 64) >= 512)
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 // backward from the forward pass's argmax codes: reads gout + 1 byte per pooled element instead of the activations
 __global__ __launch_bounds__(256) void maxpool2_bwd_code_kernel(const unsigned* __restrict__ code, int H, int W, int C4,
                                                                 const float* __restrict__ gout,
-                                                                float* __restrict__ gin) {
+                                                                float* __restrict__ gin, int accumulate) {
   const int Ho = H >> 1, Wo = W >> 1;
   const size_t total = (size_t)H * W * C4;
   const f32x4* g = reinterpret_cast<const f32x4*>(gout);
@@ -648,14 +650,14 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_code_kernel(const unsigned* 
 #pragma unroll
       for (int k = 0; k < 4; ++k) r[k] = (((cd >> (8 * k)) & 0xffu) == me) ? go[k] : 0.f;
     }
-    dst[e] = r;
+    dst[e] = accumulate ? dst[e] + r : r;
   }
 }
 // gin[y,x,c] = (this pixel is the FIRST max of its window, scan order (0,0),(0,1),(1,0),(1,1))
 //              ? gout[y/2,x/2,c] : 0, times (act > 0); pixels outside the pooled area get 0.
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ act, int H, int W, int C4,
                                                            const float* __restrict__ gout,
-                                                           float* __restrict__ gin) {
+                                                           float* __restrict__ gin, int accumulate) {
   const int Ho = H >> 1, Wo = W >> 1;
   const size_t total = (size_t)H * W * C4;
   const f32x4* a = reinterpret_cast<const f32x4*>(act);
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
         r[k] = (best == me && v[me][k] > 0.f) ? go[k] : 0.f;
       }
     }
-    dst[e] = r;
+    dst[e] = accumulate ? dst[e] + r : r;
   }
 }
 
@@ -721,11 +723,13 @@ int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float
 }
 
 int strotss_conv3x3_dgrad(const float* gout, int h, int w, int cout, const float* w_tik, int cin,
-                          const float* act_in, float* gin, void* workspace, size_t workspace_bytes, void* stream) {
+                          const float* act_in, float* gin, int accumulate, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   ST_CHECK_ARG(gout && w_tik && gin && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
   // the transposed convolution is a convolution with K = cout and N = cin
-  return conv_dispatch(gout, h, w, cout, w_tik, nullptr, cin, act_in, gin, 0, (hipStream_t)stream, workspace, workspace_bytes);
+  return conv_dispatch(gout, h, w, cout, w_tik, nullptr, cin, act_in, gin, 0, (hipStream_t)stream, workspace, workspace_bytes,
+                       accumulate);
 }
 
 int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const float* w_tic,
@@ -764,16 +768,16 @@ int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsig
 }
 
 int strotss_maxpool2_bwd(const float* act, int h, int w, int c, const float* gout, float* gin,
-                         const unsigned char* code, void* stream) {
+                         const unsigned char* code, int accumulate, void* stream) {
   ST_CHECK_ARG((act || code) && gout && gin && h >= 2 && w >= 2 && c > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(c % 4 == 0, STROTSS_EALIGN);
   const size_t total = (size_t)h * w * (c / 4);
   const dim3 grid((unsigned)min((size_t)8192, (total + 255) / 256));
   if (code)
     hipLaunchKernelGGL(maxpool2_bwd_code_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const unsigned*>(code), h, w, c / 4, gout, gin);
+                       reinterpret_cast<const unsigned*>(code), h, w, c / 4, gout, gin, accumulate);
   else
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, act, h, w, c / 4, gout, gin);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, act, h, w, c / 4, gout, gin, accumulate);
   ST_LAUNCH_RET();
 }
 

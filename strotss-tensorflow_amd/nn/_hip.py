@@ -49,7 +49,7 @@ SIGNATURES = {
     "strotss_conv3x3_c3_fwd": (_I, [_P, _I, _I, _P, _P, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
     "strotss_conv3x3_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "strotss_conv3x3_relu_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
-    "strotss_conv3x3_dgrad": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _Z, _P]),
+    "strotss_conv3x3_dgrad": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
     "strotss_conv3x3_c3_dgrad": (_I, [_P, _I, _I, _I, _P, C.POINTER(_F), _P, _I, _P]),
     "strotss_conv3x3_winograd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "strotss_conv3x3_winograd_weights": (_I, [_P, _I, _I, _I, _P, _P]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     "strotss_conv3x3_winograd_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "strotss_conv3x3_winograd_dgrad": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _P]),
     "strotss_maxpool2_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
-    "strotss_maxpool2_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "strotss_maxpool2_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "strotss_hypercol_gather": (_I, [C.POINTER(MapsT), _P, _I, _I, _P, _I, _P]),
     "strotss_hypercol_scatter": (_I, [C.POINTER(MapsT), _P, _I, _P, _I, _I, _I, _I, _P]),
     "strotss_hypercol_scatter_plan_bytes": (_Z, [_I]),

@@ -79,14 +79,19 @@ def conv3x3_relu_fwd(x, w_tok, bias, out=None):
     return out
 
 
-def conv3x3_dgrad(gout, w_tik, cin, act_in=None, out=None):
+def conv3x3_direct_splits(h: int, w: int, cin: int, cout: int) -> bool:
+    """True when a (h, w, cin -> cout) layer runs as the split-K direct kernel (which can also ADD to its output)."""
+    return _hip.load_library().strotss_conv3x3_workspace_bytes(h, w, cin, cout) > 0
+
+
+def conv3x3_dgrad(gout, w_tik, cin, act_in=None, out=None, accumulate=False):
     require(gout, "conv grad"); h, w, cout = hwc(gout)
     if out is None:
         out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
     nb = _hip.lib().strotss_conv3x3_workspace_bytes(h, w, cout, cin)
     ws = workspaces.get("conv_splitk", nb, gout.device) if nb else None
-    check(_hip.lib().strotss_conv3x3_dgrad(ptr(gout), h, w, cout, ptr(w_tik), cin, ptr(act_in), ptr(out), ptr(ws), nb,
-                                           stream_ptr()), "conv3x3_dgrad")
+    check(_hip.lib().strotss_conv3x3_dgrad(ptr(gout), h, w, cout, ptr(w_tik), cin, ptr(act_in), ptr(out), int(accumulate),
+                                           ptr(ws), nb, stream_ptr()), "conv3x3_dgrad")
     return out
 
 
@@ -246,12 +251,13 @@ def maxpool2_fwd(x, out=None, code=None):
     return out
 
 
-def maxpool2_bwd(act, gout, out=None, code=None):
-    """With `code` (from the forward pass) the activations are not read."""
+def maxpool2_bwd(act, gout, out=None, code=None, accumulate=False):
+    """With `code` (from the forward pass) the activations are not read.  accumulate: out += instead of out =."""
     require(act, "pool act"); require(gout, "pool grad"); h, w, c = hwc(act)
     if out is None:
         out = torch.empty_like(act)
-    check(_hip.lib().strotss_maxpool2_bwd(ptr(act), h, w, c, ptr(gout), ptr(out), ptr(code), stream_ptr()),
+        accumulate = False
+    check(_hip.lib().strotss_maxpool2_bwd(ptr(act), h, w, c, ptr(gout), ptr(out), ptr(code), int(accumulate), stream_ptr()),
           "maxpool2_bwd")
     return out
 

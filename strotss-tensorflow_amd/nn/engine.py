@@ -187,6 +187,20 @@ class StepEngine:
                 _ops.hypercol_scatter(self.pred_maps, None, idx, gp, relu_mask_from=1, map_begin=k,
                                       map_end=k + 1, maps_t=self._mt_pred)
 
+    def _scatter_all(self):
+        """every map's taps in one launch per region (pre-scatter backward of the small scales, nn/model.py)"""
+        n_maps = len(self.pred_maps)
+        for r in self.my_regions:
+            idx, gp = self._idx[r], self.gp[r]
+            if self.strips is not None:
+                idx, gp = idx[self._o0:self._o1], gp[self._o0:self._o1]
+            if self.deterministic:
+                _ops.hypercol_scatter_sorted(self._mt_pred, self._plans[r], int(idx.shape[0]), gp, relu_mask_from=1,
+                                             map_begin=0, map_end=n_maps)
+            else:
+                _ops.hypercol_scatter(self.pred_maps, None, idx, gp, relu_mask_from=1, map_begin=0, map_end=n_maps,
+                                      maps_t=self._mt_pred)
+
     def forward_backward(self, indices: Sequence[torch.Tensor], strip_offsets: Optional[Sequence[int]] = None) -> None:
         """train_step (run_strotss.py:131-142 / 104-125): fills self.gvars and self.scalars.
         With image strips `indices[0]` must be ordered by owning rank and `strip_offsets` be the world + 1 block
@@ -220,7 +234,7 @@ class StepEngine:
                 _ops.hypercol_scatter_plan(self._mt_pred, idx, self._plans[r])
             self._losses(r, n)
         if self.my_regions:
-            self.trunk.backward(self._scatter)
+            self.trunk.backward(self._scatter, self._scatter_all)
         else:
             self.trunk.gimg.zero_()
 
@@ -260,7 +274,7 @@ class StepEngine:
         if self.deterministic and self._o1 > self._o0:
             _ops.hypercol_scatter_plan(self._mt_pred, self._idx[0][self._o0:self._o1], self._plans[0])
         if self._o1 > self._o0:
-            self.trunk.backward(self._scatter)
+            self.trunk.backward(self._scatter, self._scatter_all)
         else:
             self.trunk.gimg.zero_()
         # rows outside the window still hold the previous step's all-reduced sum

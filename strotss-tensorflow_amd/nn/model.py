@@ -237,10 +237,37 @@ class VGGTrunk:
         if with_grad:
             # argmax codes of the pools (1 byte per pooled element): the backward pass reads them, not the activations
             self.pool_codes = [torch.empty(p.shape, dtype=torch.uint8, device=dev) for p in self.pools]
-            self.grads = [torch.empty_like(a) for a in self.acts]
+            # Small maps ("pre-scatter" backward): when EVERY tapped layer's gradient is produced by a kernel that can
+            # add to its output (the split-K direct data-gradient, the pooling backward, the first layer's pixel
+            # gradient), the taps of all maps are scattered in ONE launch into zeroed buffers before the backward pass
+            # and the producers accumulate -- 10 launches less per step at the 64 / 128 px scales.  The tapped layers'
+            # gradient buffers are then slices of one allocation (one fill).
+            self.prescatter = self._can_prescatter() and os.environ.get("STROTSS_PRESCATTER", "1") != "0"
+            if self.prescatter:
+                sizes = [a.numel() if i in set(self.taps) else 0 for i, a in enumerate(self.acts)]
+                self._tap_flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+                offs = np.cumsum([0] + sizes)
+                self.grads = [self._tap_flat[offs[i]:offs[i + 1]].view(a.shape) if sizes[i] else torch.empty_like(a)
+                              for i, a in enumerate(self.acts)]
+            else:
+                self.grads = [torch.empty_like(a) for a in self.acts]
             self.gpools = [torch.empty_like(p) for p in self.pools]
             self.gimg = torch.empty((1, h, w, 3), dtype=torch.float32, device=dev)
         self.img = None
+
+    def _can_prescatter(self) -> bool:
+        tapped = set(self.taps)
+        n = len(self.acts)
+        for step in self.plan:
+            if step[0] != 'conv':
+                continue
+            _, li, (kind, si) = step
+            if kind == 'conv' and si in tapped:           # layer li's data-gradient writes the tapped grads[si]
+                L = self.p.layers[li]
+                a = self.acts[li]
+                if self.wtile[li] != 0 or not _ops.conv3x3_direct_splits(int(a.shape[1]), int(a.shape[2]), L["cout"], L["cin"]):
+                    return False
+        return n - 1 in tapped                            # (the deepest layer is scattered into a zeroed buffer anyway)
 
     def _src(self, src):
         kind, i = src
@@ -274,21 +301,30 @@ class VGGTrunk:
                     _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
         return [self.acts[i] for i in self.taps]
 
-    def backward(self, scatter: Callable[[int], None]) -> torch.Tensor:
+    def backward(self, scatter: Callable[[int], None], scatter_all: Optional[Callable[[], None]] = None) -> torch.Tensor:
+        """scatter_all (pre-scatter mode, see __init__): adds the taps of EVERY map (incl. the image's, into gimg) in
+        one go; given and usable -> the per-layer `scatter` is not called."""
         assert self.with_grad
         P = self.p
         n_layers = len(self.acts)
         tapped = set(self.taps)
+        pre = self.prescatter and scatter_all is not None
         # the deepest layer receives gradient from its tap only
         last = n_layers - 1
-        self.grads[last].zero_()
-        scatter(last)
+        if pre:
+            self._tap_flat.zero_()
+            self.gimg.zero_()
+            scatter_all()
+            scatter = lambda li: None
+        else:
+            self.grads[last].zero_()
+            scatter(last)
         # walk the plan backwards; grads[li] always holds the ReLU-masked gradient of layer li's output
         for step in reversed(self.plan):
             if step[0] == 'pool':
                 _, pi, src_layer = step
                 _ops.maxpool2_bwd(self.acts[src_layer], self.gpools[pi], out=self.grads[src_layer],
-                                  code=self.pool_codes[pi])
+                                  code=self.pool_codes[pi], accumulate=pre and src_layer in tapped)
                 if src_layer in tapped:
                     scatter(src_layer)
             else:
@@ -296,14 +332,17 @@ class VGGTrunk:
                 L = P.layers[li]
                 kind, si = src
                 if kind == 'img':
-                    _ops.conv3x3_c3_dgrad(self.grads[li], L["w_bwd"], self.gimg, accumulate=False, std=P.std)
+                    _ops.conv3x3_c3_dgrad(self.grads[li], L["w_bwd"], self.gimg, accumulate=pre, std=P.std)
                     scatter(-1)
                 else:
                     wino = self.wtile[li] != 0
                     dgrad = _ops.conv3x3_winograd_dgrad if wino else _ops.conv3x3_dgrad
                     wts = L["u_bwd"][self.wtile[li]] if wino else L["w_bwd"]
                     if kind == 'conv':
-                        dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si])
+                        if pre and si in tapped:
+                            dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si], accumulate=True)
+                        else:
+                            dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si])
                         if si in tapped:
                             scatter(si)
                     else:

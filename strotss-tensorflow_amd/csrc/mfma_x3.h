@@ -80,6 +80,7 @@ struct X3Cfg {               // square block tile B x B, B = 128 (64 x 64 per wa
   static constexpr int LDS_BYTES = 3 * STAGE;            // 144 KiB (one workgroup per CU) | 72 KiB (two)
   static constexpr int G = B_ / 64;                      // 16-row DMA groups per wave, operand and plane
   static constexpr int NP = (3 + NPB_) * G;              // DMA pieces (1 KiB wave instructions) per wave and K-step
+  static constexpr bool K16 = false;
 };
 
 #define X3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -119,6 +120,9 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
   // DMA piece j of a K-step (NP per wave): A planes first (3 G pieces), then B's; row group j % G
   auto dma_piece = [&](int j, unsigned char* stage) {
+#ifdef X3_ABL_NO_DMA                                  // tools/x3_gemm_ablate.hip: time the loop without its loads
+    return;
+#endif
     const int pl = j / G, g = j % G;                 // pl 0..2: A planes, 3..: B planes
     unsigned char* dst = stage + pl * PL + (G * wave + g) * 1024;
     if (pl < 3) oa.dma(pl, g, dst); else ob.dma(pl - 3, g, dst);
@@ -137,6 +141,9 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
   const int b_rd = 3 * PL + (wn * HALF + l31) * 64 + ((hh ^ f) << 4);
   bf16x8 fa[2][3][T], fb[2][NPB][T];
   auto read_frags = [&](const unsigned char* stage, int kc, int slot) {
+#ifdef X3_ABL_NO_FRAG
+    if (stage != lds) return;
+#endif
     const unsigned char* pa = stage + (a_rd ^ (kc << 5));
     const unsigned char* pb = stage + (b_rd ^ (kc << 5));
 #pragma unroll
@@ -178,7 +185,11 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
         for (int im = 0; im < T; ++im) {
 #pragma unroll
           for (int in_ = 0; in_ < T; ++in_) {
+#ifndef X3_ABL_NO_MFMA
             acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][PA[q]][im], fb[c][PB[q]][in_], acc[im][in_], 0, 0, 0);
+#else
+            acc[im][in_][0] += (float)fa[c][PA[q]][im][0] + (float)fb[c][PB[q]][in_][0];
+#endif
             const int done = (q * T + im) * T + in_ + 1;       // MFMAs issued in this k-chunk
             if (MODE == 2 && c == 0 && done % STRIDE == 0 && done / STRIDE <= NP) {
               __builtin_amdgcn_sched_barrier(0);
@@ -191,7 +202,9 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
           __builtin_amdgcn_sched_barrier(0);
           if (MODE == 2) wait_one_tile_in_flight(); else X3_WAIT_VM(0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef X3_ABL_NO_BARRIER
           __builtin_amdgcn_s_barrier();
+#endif
           asm volatile("" ::: "memory");
           read_frags(s_nxt, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
@@ -205,6 +218,169 @@ __device__ __forceinline__ void x3_mainloop(unsigned char* lds, int steps, X3Ope
   for (; s + 2 < steps; ++s) kstep(std::integral_constant<int, 2>{});
   if (steps > 1) kstep(std::integral_constant<int, 1>{});
   kstep(std::integral_constant<int, 0>{});
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 128 x 128 tiles, TWO workgroups per CU: K-step 16 (ONE MFMA k-chunk), stage = 6 images of [128 rows][32 B] = 24 KiB,
+// three-stage ring = 72 KiB.  The 32-KiB-step form above holds 144 KiB and runs alone on its CU: its prologue (first
+// tiles from L2 / HBM), its epilogue (64 KiB of stores) and every barrier are exposed -- tools/x3_gemm_ablate.hip: the MFMA
+// stream alone, no loads at all, takes 79 of the 92 us of a 36 x (1024 x 512 x 512) product whose MFMAs are 46 us of work.
+// With two co-resident workgroups (two waves per SIMD) one computes while the other fills, stores or waits; the operand
+// bytes per MFMA stay those of the 128 tile (half the 64 x 64 form's).
+// A DMA wave instruction (64 lanes x 16 B) covers 32 rows x 32 B: wave w stages rows [32 w, 32 w + 32) of each image.
+// Rows are 32 B; the two 16-byte slots of a row are swapped in rows with (row >> 3) & 1 (on the DMA's source address and
+// on the fragment read), so 16 consecutive lanes of a ds_read_b128 (16 rows, one k-half) cover all 64 banks once.
+// Per step s: the 6 DMA pieces of tile s+2 behind the first MFMAs (its stage is free since the barrier of step s-1),
+// MFMAs 0..15 on the fragments of tile s, `s_waitcnt vmcnt(6)` (tile s+1 landed, tile s+2 stays in flight) + barrier,
+// the fragments of tile s+1 into the other register slot, MFMAs 16..23.
+template <int NPB_ = 3>
+struct X3CfgK16 {
+  static_assert(NPB_ == 3, "K16 ring: three B planes");
+  static constexpr int NPB = NPB_, NPROD = 6;
+  static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, NT = 256;
+  static constexpr int T = 2, TM = 2, TN = 2;
+  static constexpr int PL = 128 * 32;                    // bytes of one plane image ([128 rows][32 B])
+  static constexpr int STAGE = 6 * PL;                   // 24 KiB
+  static constexpr int LDS_BYTES = 3 * STAGE;            // 72 KiB: two workgroups per CU
+  static constexpr int G = 1, NP = 6;
+  static constexpr bool K16 = true;
+};
+
+struct X3OperandK16 {
+  const char* base;
+  unsigned off;              // this lane's 16-byte chunk of its row: row * 64 + (lane & 1) * 16
+  unsigned plane;            // bytes per plane panel (rows * 64)
+  unsigned cur;              // byte offset of the current K-block's first plane (+ 32 in its second half)
+  __device__ __forceinline__ X3OperandK16(const __bf16* p, int rows, int row0) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    base = reinterpret_cast<const char*>(p);
+    plane = (unsigned)rows * 64u;
+    cur = 0;
+    const int row = min(row0 + wave * 32 + (lane >> 1), rows - 1);
+    // LDS slot (lane & 1) of tile row (lane >> 1) holds source chunk slot ^ ((row >> 3) & 1): see the fragment reads
+    off = (unsigned)row * 64u + (unsigned)((lane & 1) ^ ((lane >> 4) & 1)) * 16u;
+  }
+  __device__ __forceinline__ void dma(int pl, unsigned char* lds_dst) const {
+    const char* src = base + (size_t)(cur + pl * plane) + off;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+  }
+  // half 0 -> 1: the other 32 bytes of the same rows; half 1 -> 0: next K-block
+  __device__ __forceinline__ void advance(int half) { cur += half ? 3u * plane - 32u : 32u; }
+};
+
+template <class Cfg> struct X3Ops {
+  using A = std::conditional_t<Cfg::K16, X3OperandK16, X3Operand<Cfg::G, 3>>;
+  using B = std::conditional_t<Cfg::K16, X3OperandK16, X3Operand<Cfg::G, Cfg::NPB>>;
+};
+
+// The first two tiles' DMA of a product (steps >= 2, even): separate from the loop so that a persistent workgroup can
+// put the NEXT product's first loads in flight before it stores the current one (gemm_x3_persistent_kernel).
+template <class Cfg>
+__device__ __forceinline__ void x3_k16_prologue(unsigned char* lds, X3OperandK16& oa, X3OperandK16& ob) {
+#ifndef X3_ABL_NO_DMA
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    unsigned char* stage = lds + h * Cfg::STAGE;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      unsigned char* dst = stage + j * Cfg::PL + wave * 1024;
+      if (j < 3) oa.dma(j, dst); else ob.dma(j - 3, dst);
+    }
+    oa.advance(h); ob.advance(h);
+  }
+#endif
+}
+
+// After x3_k16_prologue.  Stores issued between the prologue and this loop (the persistent kernel's epilogue) do not
+// break the first wait: loads return in order among themselves, so "at most 6 operations outstanding" still means that
+// at most the 6 youngest LOADS (tile 1's) are, i.e. tile 0 has landed.
+template <class Cfg>
+__device__ __forceinline__ void x3_mainloop_k16(unsigned char* lds, int steps, X3OperandK16& oa, X3OperandK16& ob,
+                                                f32x16 (&acc)[2][2]) {
+  constexpr int PL = Cfg::PL, STAGE = Cfg::STAGE;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+  auto dma_piece = [&](int j, unsigned char* stage) {        // j 0..2: A planes, 3..5: B planes; this wave's 32 rows
+#ifdef X3_ABL_NO_DMA
+    return;
+#endif
+    unsigned char* dst = stage + j * PL + wave * 1024;
+    if (j < 3) oa.dma(j, dst); else ob.dma(j - 3, dst);
+  };
+  int half = 0;
+  const int sw = (hh ^ ((l31 >> 3) & 1)) << 4;
+  const int a_rd = (wm * 64 + l31) * 32 + sw;
+  const int b_rd = 3 * PL + (wn * 64 + l31) * 32 + sw;
+  bf16x8 fa[2][3][2], fb[2][3][2];
+  auto read_frags = [&](const unsigned char* stage, int slot) {
+#ifdef X3_ABL_NO_FRAG
+    if (stage != lds) return;
+#endif
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[slot][p][i] = *reinterpret_cast<const bf16x8*>(stage + a_rd + p * PL + i * 1024);
+        fb[slot][p][i] = *reinterpret_cast<const bf16x8*>(stage + b_rd + p * PL + i * 1024);
+      }
+    }
+  };
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+  unsigned char* s_cur = lds;
+  unsigned char* s_nxt = lds + STAGE;
+  unsigned char* s_nn = lds + 2 * STAGE;
+  X3_WAIT_VM(6);
+  __builtin_amdgcn_s_barrier();
+  read_frags(s_cur, 0);
+
+  // MODE 2: tile s+2 exists; 1: tile s+1 is the last; 0: last step.  SLOT: register slot of this step's fragments
+  auto kstep = [&](auto mode_tag, auto slot_tag) {
+    constexpr int MODE = decltype(mode_tag)::value, SLOT = decltype(slot_tag)::value;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+      for (int im = 0; im < 2; ++im) {
+#pragma unroll
+        for (int in_ = 0; in_ < 2; ++in_) {
+#ifndef X3_ABL_NO_MFMA
+          acc[im][in_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SLOT][PA[q]][im], fb[SLOT][PB[q]][in_], acc[im][in_], 0, 0, 0);
+#else
+          acc[im][in_][0] += (float)fa[SLOT][PA[q]][im][0] + (float)fb[SLOT][PB[q]][in_][0];
+#endif
+          const int done = (q * 2 + im) * 2 + in_ + 1;
+          if (MODE == 2 && done <= 6) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(done - 1, s_nn);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (q == 3 && MODE != 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 2) X3_WAIT_VM(6); else X3_WAIT_VM(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef X3_ABL_NO_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+        read_frags(s_nxt, SLOT ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (MODE == 2) { oa.advance(half); ob.advance(half); half ^= 1; }
+    unsigned char* tmp = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = tmp;
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  // steps is even (K % 32 == 0): two steps per trip keep the register slots static
+  int s = 0;
+  for (; s + 3 < steps; s += 2) { kstep(I2{}, I0{}); kstep(I2{}, I1{}); }
+  // s + 2 == steps here
+  kstep(I1{}, I0{});
+  kstep(I0{}, I1{});
 }
 
 // Default "no prefetch" protocol for epilogues: derive from X3NoPrefetch<Derived> (CRTP) to get Pre / prefetch / the
@@ -259,8 +435,8 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
     }
   }
   epi.set_batch(bz);
-  X3Operand<Cfg::G, 3> oa(A + (long long)bz * strideA, M, m0);
-  X3Operand<Cfg::G, Cfg::NPB> ob(B + (long long)bz * strideB, N, n0);
+  typename X3Ops<Cfg>::A oa(A + (long long)bz * strideA, M, m0);
+  typename X3Ops<Cfg>::B ob(B + (long long)bz * strideB, N, n0);
   f32x16 acc[Cfg::T][Cfg::T];
 #pragma unroll
   for (int i = 0; i < Cfg::T; ++i)
@@ -279,7 +455,8 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
         epi.prefetch(pre, im, in, reg, m0 + map.row(im, reg), n0 + map.colof(in));
-  x3_mainloop<Cfg>(lds, K >> 5, oa, ob, acc);
+  if constexpr (Cfg::K16) { x3_k16_prologue<Cfg>(lds, oa, ob); x3_mainloop_k16<Cfg>(lds, K >> 4, oa, ob, acc); }
+  else x3_mainloop<Cfg>(lds, K >> 5, oa, ob, acc);
   float local = 0.f;
 #pragma unroll
   for (int im = 0; im < Cfg::T; ++im)
@@ -295,6 +472,70 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
   }
   __syncthreads();
   epi.finish(reinterpret_cast<float*>(lds), local);
+}
+
+// PERSISTENT form of the batched product (K16 ring, two workgroups per CU, plain store epilogues): the launch holds
+// 2 x 256 workgroups (or fewer) and each walks a strided list of tiles.  A workgroup of the one-tile kernel pays about
+// 5 us of launch, first-tile latency and store time around 11 us of MFMAs (36 x (1024 x 512 x 512), tools/x3_gemm_ablate
+// .hip); here the next tile's first loads are in flight while the current tile is stored, and nothing is relaunched.
+// XCD x (workgroups x, x + 8, ...) owns the contiguous tile range [x, x + 1) * ceil(tiles / 8): its 64 workgroups walk
+// 64 consecutive tiles at a time (N-tile fastest, then M-tile, then batch), so an XCD's L2 holds the panels it streams.
+template <class Cfg, class Epi>
+__global__ __launch_bounds__(Cfg::NT) void gemm_x3_persistent_kernel(const __bf16* __restrict__ A, int M, long long strideA,
+                                                                     const __bf16* __restrict__ B, int N, long long strideB,
+                                                                     int K, int batch, Epi epi) {
+  static_assert(Cfg::K16 && !Epi::SYMM, "persistent form: K16 ring, store epilogues");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDS_BYTES];
+  const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
+  const unsigned total = gx * gy * (unsigned)batch;
+  const unsigned x = blockIdx.x & 7, slot = blockIdx.x >> 3, per_x = gridDim.x >> 3;     // gridDim.x % 8 == 0
+  const unsigned chunk = (total + 7) / 8;
+  const unsigned hi = min(total, (x + 1) * chunk);
+  unsigned tile = x * chunk + slot;
+  if (tile >= hi) return;
+  auto locate = [&](unsigned tl, unsigned& bz, int& m0, int& n0) {
+    bz = tl / (gx * gy);
+    const unsigned rem = tl - bz * (gx * gy);
+    m0 = (int)(rem / gx) * Cfg::BM; n0 = (int)(rem % gx) * Cfg::BN;
+  };
+  unsigned bz; int m0, n0;
+  locate(tile, bz, m0, n0);
+  PipeAccMap<Cfg> map;
+  {
+    X3OperandK16 oa(A + (long long)bz * strideA, M, m0), ob(B + (long long)bz * strideB, N, n0);
+    x3_k16_prologue<Cfg>(lds, oa, ob);
+    for (;;) {
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      x3_mainloop_k16<Cfg>(lds, K >> 4, oa, ob, acc);
+      const unsigned cbz = bz; const int cm0 = m0, cn0 = n0;
+      tile += per_x;
+      const bool more = tile < hi;
+      // every wave's fragment reads are complete (the last step used registers only): the ring is free
+      __builtin_amdgcn_s_barrier();
+      if (more) {
+        locate(tile, bz, m0, n0);
+        oa = X3OperandK16(A + (long long)bz * strideA, M, m0);
+        ob = X3OperandK16(B + (long long)bz * strideB, N, n0);
+        x3_k16_prologue<Cfg>(lds, oa, ob);
+      }
+      epi.set_batch(cbz);
+      typename Epi::template Pre<Cfg::T> pre;
+#pragma unroll
+      for (int im = 0; im < 2; ++im)
+#pragma unroll
+        for (int in = 0; in < 2; ++in)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            epi.apply(pre, im, in, reg, cm0 + map.row(im, reg), cn0 + map.colof(in), acc[im][in][reg]);
+      if (!more) break;
+    }
+  }
 }
 
 // Row-major f32 (rows x ld, K <= ld columns used, K % 32 == 0) -> x3 panels, batched over blockIdx.y.

@@ -241,6 +241,32 @@ def test_deterministic_mode_is_bitwise_reproducible():
         assert float((a - b).norm() / a.norm()) < 1e-5
 
 
+def test_prescatter_backward_equals_the_interleaved_one():
+    """Small scales (nn/model.py VGGTrunk: every tapped layer's gradient comes from an accumulating producer): all maps'
+    taps land in ONE scatter launch before the backward pass.  Same kernels and inputs otherwise -> the pixel gradient
+    equals the interleaved form's to summation-order rounding; the deterministic engine (no atomics) must agree too."""
+    S = _setup(64, 64, 384, seed=5)
+    eng = S["eng"]
+    assert eng.trunk.prescatter, "64 px: all tapped layers' producers are split-K direct dgrads or pool backwards"
+    i0 = torch.from_numpy(S["idx_sets"][0][0]).to(DEV)
+    eng.forward_backward([i0])
+    pre = [g.clone() for g in eng.gvars]
+    eng.trunk.prescatter = False
+    eng.forward_backward([i0])
+    for a, b in zip(pre, eng.gvars):
+        assert float((a - b).norm() / b.norm()) < 1e-5
+    eng.trunk.prescatter = True
+    from nn import engine as E
+    det = E.StepEngine(eng.params, eng.content_feat, eng.style_targets, eng.stylized(), eng.alpha, eng.loss_denom, eng.lr,
+                       sample_size=384, deterministic=True)
+    det.forward_backward([i0])
+    for a, b in zip(pre, det.gvars):
+        assert float((a - b).norm() / b.norm()) < 1e-5
+    # a big map keeps the interleaved scatter (Winograd data-gradients overwrite their output)
+    S = _setup(256, 256, 256, seed=5)
+    assert not S["eng"].trunk.prescatter
+
+
 # ------------------------------------------------------------------ operator surface (autograd)
 def test_losses_api_autograd():
     from nn import losses as L

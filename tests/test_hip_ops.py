@@ -124,6 +124,15 @@ def test_conv_generic_fwd_and_dgrad(ops, cfg):
         assert rel_err(got, xin.grad.numpy()) < 3e-6
         got = ops.conv3x3_dgrad(dev(gy), dev(w_tik), cin, act_in=dev(x)).cpu().numpy()
         assert rel_err(got, (xin.grad * (x > 0)).numpy()) < 3e-6
+        # accumulate (pre-scatter backward): the split-K form adds the masked gradient to its output, the big-map
+        # form refuses instead of silently overwriting
+        base = torch.randn(x.shape, generator=g, dtype=torch.float64).float()
+        if ops.conv3x3_direct_splits(h, w, cout, cin):
+            acc = ops.conv3x3_dgrad(dev(gy), dev(w_tik), cin, act_in=dev(x), out=dev(base).clone(), accumulate=True)
+            assert np.array_equal(acc.cpu().numpy(), base.numpy() + got)
+        else:
+            with pytest.raises(RuntimeError):
+                ops.conv3x3_dgrad(dev(gy), dev(w_tik), cin, act_in=dev(x), out=dev(base).clone(), accumulate=True)
 
 
 @pytest.mark.parametrize("cfg", [(16, 24, 128, 256), (9, 7, 256, 256), (5, 3, 512, 512), (33, 20, 64, 64),
@@ -218,6 +227,11 @@ def test_maxpool(ops, hwc):
     assert int(code.max()) <= 4
     got2 = ops.maxpool2_bwd(dev(x), dev(gy), code=code).cpu().numpy()
     assert np.array_equal(got2, got)
+    # accumulate: out += (the taps' contributions are already in the buffer, nn/model.py pre-scatter)
+    base = torch.randn(x.shape, generator=g, dtype=torch.float64).float()
+    for kw in (dict(), dict(code=code)):
+        acc = ops.maxpool2_bwd(dev(x), dev(gy), out=dev(base).clone(), accumulate=True, **kw).cpu().numpy()
+        assert np.array_equal(acc, base.numpy() + got)
 
 
 # ------------------------------------------------------------------ hypercolumns

@@ -408,7 +408,14 @@ struct X3Mirror {       // writes the transpose of the workgroup's tile through 
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
                        int batch, hipStream_t s, long min_tiles128) {
   EpiScaleStoreX3 e{{C, ldc, M, N, 1.0f, strideC}, {}};
-  if ((long)cdiv(N, 128) * cdiv(M, 128) * batch >= min_tiles128) {
+  static const bool k16 = [] { const char* v = getenv("STROTSS_X3_K16"); return !v || atoi(v) != 0; }();
+  if ((long)cdiv(N, 128) * cdiv(M, 128) * batch >= min_tiles128 && k16) {
+    // two co-resident workgroups per CU (K-step 16, 72 KiB ring): one computes while the other fills, stores or waits
+    using Cfg = X3CfgK16<3>;
+    dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
+    hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStoreX3, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,
+                       (long long)3 * M * K, (const __bf16*)B, N, (long long)3 * N * K, K, e, X3NoMirror{});
+  } else if ((long)cdiv(N, 128) * cdiv(M, 128) * batch >= min_tiles128) {
     using Cfg = X3Cfg<128>;
     dim3 grid((unsigned)cdiv(N, 128) * cdiv(M, 128) * batch);
     hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiScaleStoreX3, X3NoMirror>), grid, dim3(Cfg::NT), 0, s, (const __bf16*)A, M,

@@ -274,8 +274,8 @@ template <class Cfg> struct X3Ops {
   using B = std::conditional_t<Cfg::K16, X3OperandK16, X3Operand<Cfg::G, Cfg::NPB>>;
 };
 
-// The first two tiles' DMA of a product (steps >= 2, even): separate from the loop so that a persistent workgroup can
-// put the NEXT product's first loads in flight before it stores the current one (gemm_x3_persistent_kernel).
+// The first two tiles' DMA of a product (steps >= 2, even).  Separate from the loop: a persistent workgroup can put the NEXT
+// product's first loads in flight before it stores the current one (tools/x3_gemm_ablate.hip; measured: no gain).
 template <class Cfg>
 __device__ __forceinline__ void x3_k16_prologue(unsigned char* lds, X3OperandK16& oa, X3OperandK16& ob) {
 #ifndef X3_ABL_NO_DMA
@@ -293,7 +293,7 @@ __device__ __forceinline__ void x3_k16_prologue(unsigned char* lds, X3OperandK16
 #endif
 }
 
-// After x3_k16_prologue.  Stores issued between the prologue and this loop (the persistent kernel's epilogue) do not
+// After x3_k16_prologue.  Stores issued between the prologue and this loop (a persistent kernel's epilogue) would not
 // break the first wait: loads return in order among themselves, so "at most 6 operations outstanding" still means that
 // at most the 6 youngest LOADS (tile 1's) are, i.e. tile 0 has landed.
 template <class Cfg>
@@ -472,70 +472,6 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
   }
   __syncthreads();
   epi.finish(reinterpret_cast<float*>(lds), local);
-}
-
-// PERSISTENT form of the batched product (K16 ring, two workgroups per CU, plain store epilogues): the launch holds
-// 2 x 256 workgroups (or fewer) and each walks a strided list of tiles.  A workgroup of the one-tile kernel pays about
-// 5 us of launch, first-tile latency and store time around 11 us of MFMAs (36 x (1024 x 512 x 512), tools/x3_gemm_ablate
-// .hip); here the next tile's first loads are in flight while the current tile is stored, and nothing is relaunched.
-// XCD x (workgroups x, x + 8, ...) owns the contiguous tile range [x, x + 1) * ceil(tiles / 8): its 64 workgroups walk
-// 64 consecutive tiles at a time (N-tile fastest, then M-tile, then batch), so an XCD's L2 holds the panels it streams.
-template <class Cfg, class Epi>
-__global__ __launch_bounds__(Cfg::NT) void gemm_x3_persistent_kernel(const __bf16* __restrict__ A, int M, long long strideA,
-                                                                     const __bf16* __restrict__ B, int N, long long strideB,
-                                                                     int K, int batch, Epi epi) {
-  static_assert(Cfg::K16 && !Epi::SYMM, "persistent form: K16 ring, store epilogues");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDS_BYTES];
-  const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
-  const unsigned total = gx * gy * (unsigned)batch;
-  const unsigned x = blockIdx.x & 7, slot = blockIdx.x >> 3, per_x = gridDim.x >> 3;     // gridDim.x % 8 == 0
-  const unsigned chunk = (total + 7) / 8;
-  const unsigned hi = min(total, (x + 1) * chunk);
-  unsigned tile = x * chunk + slot;
-  if (tile >= hi) return;
-  auto locate = [&](unsigned tl, unsigned& bz, int& m0, int& n0) {
-    bz = tl / (gx * gy);
-    const unsigned rem = tl - bz * (gx * gy);
-    m0 = (int)(rem / gx) * Cfg::BM; n0 = (int)(rem % gx) * Cfg::BN;
-  };
-  unsigned bz; int m0, n0;
-  locate(tile, bz, m0, n0);
-  PipeAccMap<Cfg> map;
-  {
-    X3OperandK16 oa(A + (long long)bz * strideA, M, m0), ob(B + (long long)bz * strideB, N, n0);
-    x3_k16_prologue<Cfg>(lds, oa, ob);
-    for (;;) {
-      f32x16 acc[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      x3_mainloop_k16<Cfg>(lds, K >> 4, oa, ob, acc);
-      const unsigned cbz = bz; const int cm0 = m0, cn0 = n0;
-      tile += per_x;
-      const bool more = tile < hi;
-      // every wave's fragment reads are complete (the last step used registers only): the ring is free
-      __builtin_amdgcn_s_barrier();
-      if (more) {
-        locate(tile, bz, m0, n0);
-        oa = X3OperandK16(A + (long long)bz * strideA, M, m0);
-        ob = X3OperandK16(B + (long long)bz * strideB, N, n0);
-        x3_k16_prologue<Cfg>(lds, oa, ob);
-      }
-      epi.set_batch(cbz);
-      typename Epi::template Pre<Cfg::T> pre;
-#pragma unroll
-      for (int im = 0; im < 2; ++im)
-#pragma unroll
-        for (int in = 0; in < 2; ++in)
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg)
-            epi.apply(pre, im, in, reg, cm0 + map.row(im, reg), cn0 + map.colof(in), acc[im][in][reg]);
-      if (!more) break;
-    }
-  }
 }
 
 // Row-major f32 (rows x ld, K <= ld columns used, K % 32 == 0) -> x3 panels, batched over blockIdx.y.

@@ -461,46 +461,58 @@ __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_kernel(const float* __re
 }
 
 // ---- first layer on the MFMA (cout == 64): one wave = 32 pixels x 64 channels, K = 27 (+1 zero) as 14
-// v_mfma_f32_32x32x2_f32 per 32-channel half.  A (pixels x taps) is gathered straight from the 12-byte pixels
-// with the preprocess applied in flight; B (taps x channels) sits in LDS.  HBM-bound on its 256-byte rows.
+// v_mfma_f32_32x32x2_f32 per 32-channel half; B (taps x channels) sits in LDS.
+// A workgroup owns 128 consecutive pixels of one image row per trip.  The f32 MFMA does not co-issue with the VALU on
+// gfx950, so every address / bounds / preprocess instruction of the A gather is paid in MFMA time: the 3 x 130 pixel
+// patch is therefore staged ONCE per trip, preprocessed and zero-padded, in LDS (one bounds check and one preprocess per
+// patch element instead of nine), and the 14 A values of a lane are plain ds_reads at compile-time offsets.
+// The wave's 32 pixels x 64 channels are 8 KiB of CONSECUTIVE output: through LDS (row stride 68 floats: the two lane
+// halves, 4 rows apart, land 16 banks apart) into eight contiguous 1-KiB dwordx4 stores.  HBM-bound on its 256-byte rows.
+#define C3F_RS 68       // LDS row stride of the output staging, floats
+#define C3F_SEG 128     // pixels per workgroup trip
+#define C3F_PW (C3F_SEG + 2)
 __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* __restrict__ img, int H, int W,
                                                                   const float* __restrict__ w_kio,
                                                                   const float* __restrict__ bias,
                                                                   f32x4 mean_, f32x4 istd_, float* __restrict__ out) {
   __shared__ float wsm[28 * 64];
+  __shared__ float patch[3 * C3F_PW * 3];
+  __shared__ __attribute__((aligned(16))) float stage[4 * 32 * C3F_RS];
   for (int i = threadIdx.x; i < 28 * 64; i += 256) wsm[i] = (i < 27 * 64) ? w_kio[i] : 0.f;
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int HW = H * W;
-  const int groups = (HW + 31) / 32;
-  const float mean[3] = {mean_[0], mean_[1], mean_[2]}, istd[3] = {istd_[0], istd_[1], istd_[2]};
+  const int segs_x = (W + C3F_SEG - 1) / C3F_SEG;
+  const int trips = H * segs_x;
   const float b0 = bias[l31], b1 = bias[32 + l31];
-  for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
-    const int p = g * 32 + l31;
-    const bool live = p < HW;
-    const int y = live ? p / W : 0, x = live ? p - y * W : 0;
+  float* st = stage + wave * (32 * C3F_RS);
+  for (int trip = blockIdx.x; trip < trips; trip += gridDim.x) {
+    const int y = trip / segs_x, x0 = (trip - y * segs_x) * C3F_SEG;
+    __syncthreads();                                   // the previous trip's A reads are done (first trip: wsm visible)
+    for (int e = threadIdx.x; e < 3 * C3F_PW * 3; e += 256) {
+      const int r = e / (C3F_PW * 3), rem = e - r * (C3F_PW * 3);
+      const int px = rem / 3, ch = rem - px * 3;
+      const int yy = y + r - 1, xx = x0 + px - 1;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const float v = img[ok ? ((size_t)yy * W + xx) * 3 + ch : 0];
+      const float m = ch == 0 ? mean_[0] : (ch == 1 ? mean_[1] : mean_[2]);
+      const float is = ch == 0 ? istd_[0] : (ch == 1 ? istd_[1] : istd_[2]);
+      patch[e] = ok ? (v - m) * is : 0.f;
+    }
+    __syncthreads();
+    const int xw = x0 + wave * 32;                     // this wave's 32 pixels
+    if (xw >= W) continue;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
-    // all 14 gathers of this lane first, branch-free (clamped address, zero-select afterwards): behind a branch
-    // every load would be followed by its own s_waitcnt and the 14 latencies would add up
-    float av[14];
-    bool okv[14];
-    int chv[14];
+    // this lane's k = 2*s2 + hh -> (tap, ch) = (k / 3, k % 3) -> patch offset (tap / 3) * PW * 3 + (tap % 3) * 3 + ch
+    // = k + (k / 9) * (PW * 3 - 9); relative to the lane's pixel: + (wave * 32 + l31) * 3
+    const float* pl = patch + (wave * 32 + l31) * 3;
 #pragma unroll
     for (int s2 = 0; s2 < 14; ++s2) {
-      // this lane's k = 2*s2 + hh  ->  (tap, channel); both candidates are compile-time, hh selects
-      const int k0 = 2 * s2, k1 = 2 * s2 + 1;
-      const int tap = hh ? k1 / 3 : k0 / 3, ch = hh ? k1 % 3 : k0 % 3;
-      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-      const bool ok = live && tap < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      okv[s2] = ok; chv[s2] = ch;
-      av[s2] = img[ok ? ((size_t)yy * W + xx) * 3 + ch : 0];
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 14; ++s2) {
-      const float a = okv[s2] ? (av[s2] - mean[chv[s2]]) * istd[chv[s2]] : 0.f;
+      constexpr int ROWJ = C3F_PW * 3 - 9;
+      const int o0 = 2 * s2 + ((2 * s2) / 9) * ROWJ, o1 = 2 * s2 + 1 + ((2 * s2 + 1) / 9) * ROWJ;
+      const float av = pl[(hh && s2 != 13) ? o1 : o0];
+      const float a = (s2 == 13 && hh) ? 0.f : av;     // k = 27 is the zero tap
       const float w0 = wsm[(2 * s2 + hh) * 64 + l31], w1 = wsm[(2 * s2 + hh) * 64 + 32 + l31];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc1, 0, 0, 0);
@@ -508,11 +520,17 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* _
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-      const int pp = g * 32 + row;
-      if (pp < HW) {
-        out[(size_t)pp * 64 + l31] = fmaxf(acc0[reg], 0.f);
-        out[(size_t)pp * 64 + 32 + l31] = fmaxf(acc1[reg], 0.f);
-      }
+      st[row * C3F_RS + l31] = fmaxf(acc0[reg], 0.f);
+      st[row * C3F_RS + 32 + l31] = fmaxf(acc1[reg], 0.f);
+    }
+    // (same wave wrote and reads: no barrier; the compiler orders the LDS accesses with lgkmcnt)
+    const int r4 = lane >> 4, c4 = lane & 15;
+    float* orow = out + ((size_t)y * W + xw) * 64;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + r4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * C3F_RS + c4 * 4);
+      if (xw + row < W) *reinterpret_cast<f32x4*>(orow + (size_t)row * 64 + c4 * 4) = v;
     }
   }
 }
@@ -699,8 +717,8 @@ int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, c
   const f32x4 m = {mean3[0], mean3[1], mean3[2], 0.f};
   const f32x4 is = {1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2], 0.f};
   if (cout == 64 && conv_variant() != 1) {
-    const int groups = cdiv((int64_t)h * w, 32);
-    hipLaunchKernelGGL(conv3x3_c3_fwd_mfma_kernel, dim3(min(4096, cdiv(groups, 4))), dim3(256), 0, (hipStream_t)stream,
+    const int trips = h * cdiv(w, C3F_SEG);
+    hipLaunchKernelGGL(conv3x3_c3_fwd_mfma_kernel, dim3(min(2048, trips)), dim3(256), 0, (hipStream_t)stream,
                        img, h, w, w_kio, bias, m, is, out);
     ST_LAUNCH_RET();
   }

@@ -8,6 +8,8 @@
 #include "internal.h"
 #include "mfma_pipe.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 namespace {
 
 // out[p, co] = epilogue( sum_{tap,ci} in[p + tap offset, ci] * wt[tap][co][ci] )
@@ -576,24 +578,25 @@ __global__ __launch_bounds__(512) void conv3x3_c3_dgrad_lds_kernel(const float* 
   const int cq = wave & 3, lp = (wave >> 2) * 64 + lane;          // 128 pixels
   const int ly = lp / C3D_TW, lx = lp - ly * C3D_TW;
   const float* wq = w_tic + cq * 16;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  // every accumulator is a PAIR over even / odd channels: (gv[k], gv[k+1]) * (w[k], w[k+1]) are adjacent registers on
+  // both sides, so all 432 FMAs of a lane are 216 v_pk_fma_f32 with an SGPR-pair operand and nothing to shuffle
+  f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const float* q = &tile[((ly + tap / 3) * (C3D_TW + 2) + lx + tap % 3) * C3D_PS + cq * 16];
-    const float* w0 = wq + (tap * 3 + 0) * 64;
-    const float* w1 = wq + (tap * 3 + 1) * 64;
-    const float* w2 = wq + (tap * 3 + 2) * 64;
+    const f32x2* w0 = reinterpret_cast<const f32x2*>(wq + (tap * 3 + 0) * 64);
+    const f32x2* w1 = reinterpret_cast<const f32x2*>(wq + (tap * 3 + 1) * 64);
+    const f32x2* w2 = reinterpret_cast<const f32x2*>(wq + (tap * 3 + 2) * 64);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 gv = *reinterpret_cast<const f32x4*>(q + 4 * g);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        s0 += gv[k] * w0[4 * g + k];
-        s1 += gv[k] * w1[4 * g + k];
-        s2 += gv[k] * w2[4 * g + k];
-      }
+      const f32x2 lo = {gv[0], gv[1]}, hi = {gv[2], gv[3]};
+      p0 = __builtin_elementwise_fma(lo, w0[2 * g], p0); p0 = __builtin_elementwise_fma(hi, w0[2 * g + 1], p0);
+      p1 = __builtin_elementwise_fma(lo, w1[2 * g], p1); p1 = __builtin_elementwise_fma(hi, w1[2 * g + 1], p1);
+      p2 = __builtin_elementwise_fma(lo, w2[2 * g], p2); p2 = __builtin_elementwise_fma(hi, w2[2 * g + 1], p2);
     }
   }
+  const float s0 = p0[0] + p0[1], s1 = p1[0] + p1[1], s2 = p2[0] + p2[1];
   __shared__ float red[4][C3D_TH * C3D_TW][3];
   red[cq][lp][0] = s0; red[cq][lp][1] = s1; red[cq][lp][2] = s2;
   __syncthreads();

@@ -13,8 +13,12 @@ import numpy as np
 import torch
 
 
-def problem(dev, world_group, h=96, w=128, regions=3, n_samples=256):
-    """Deterministic masked problem, identical in every process."""
+def problem(dev, world_group, h=96, w=128, regions=3, n_samples=256, deterministic=True):
+    """Deterministic masked problem, identical in every process.
+    deterministic=True: the tap adjoint as the sorted scatter.  Two processes share ONE GPU in this test, and under that
+    contention the float-atomic scatter kernel was measured to lose updates in about one launch in ten (cache-line sized
+    pieces of the sum, 1e-3..3e-2 of the gradient norm; never with the GPU to itself, never in the sorted scatter, never
+    in stand-alone atomic probes -- DESIGN.md 6).  One process per GPU, the deployment, does not share."""
     from nn import _ops, engine, strotss_utils as SU
     from nn.model import VGGParams, synthetic_weights
 
@@ -39,7 +43,7 @@ def problem(dev, world_group, h=96, w=128, regions=3, n_samples=256):
     init = SU.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
     alpha = 4.0
     eng = engine.StepEngine(params, cfeat, targets, init, alpha, 2.0 + alpha + 1.0 / alpha, 2e-3, sample_size=n_samples,
-                            dist_group=world_group)
+                            dist_group=world_group, deterministic=deterministic)
     idx = [[torch.from_numpy(SU.make_indices_np(h, w, True, n_samples, rng, m)).to(dev) for m in masks] for _ in range(3)]
     return eng, idx
 

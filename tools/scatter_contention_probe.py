@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Does the float-atomic tap adjoint give the same sum every time?
+
+Repeats ONE hypercol_scatter launch on fixed inputs (the deepest map of a 96 x 128 masked problem) and compares with the
+first result.  With the GPU to itself: deviations of 1e-7 (summation order).  With a second process running optimisation
+steps on the same GPU (start this script twice): about one launch in ten is off by 1e-3 .. 5e-2 of the norm, in pieces of
+whole cache lines, although its inputs are bitwise unchanged and every launch is bracketed by device synchronisations.
+tools/atomic_probe.hip (plain float atomics with the same address patterns and lane masks) stays exact under the same
+contention, system-scope atomics change nothing, and the sorted scatter (STROTSS_DETERMINISTIC=1) stays bitwise equal.
+Cause not found; DESIGN.md 6 has the record.  Usage: python tools/scatter_contention_probe.py ITERATIONS [all|one|nomask]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "strotss-tensorflow_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+import _region_worker as W
+from nn import _hip, _ops
+dev = torch.device("cuda", 0)
+eng, idx = W.problem(dev, None, deterministic=False)
+tr = eng.trunk
+last = len(tr.acts) - 1
+eng.forward_backward(idx[0])
+torch.cuda.synchronize()
+k = eng._layer_to_map[last]
+mode = sys.argv[2] if len(sys.argv) > 2 else "all"
+ref = None; bad = 0; worst = 0.0
+g = tr.grads[last]
+for it in range(int(sys.argv[1])):
+    g.zero_()
+    torch.cuda.synchronize()
+    for r in ([0] if mode == "one" else eng.my_regions):
+        _ops.hypercol_scatter(eng.pred_maps, None, eng._idx[r], eng.gp[r], relu_mask_from=(99 if mode == "nomask" else 1),
+                              map_begin=k, map_end=k + 1, maps_t=eng._mt_pred)
+    torch.cuda.synchronize()
+    v = g.clone()
+    torch.cuda.synchronize()
+    vc = g.cpu()
+    v2 = g.clone(); torch.cuda.synchronize()
+    if not torch.equal(v.cpu(), vc) or not torch.equal(v2, v):
+        print("iter", it, "READS DISAGREE: clone vs cpu rel %.3g, clone vs second clone rel %.3g" % (
+              float((v.cpu() - vc).norm() / vc.norm()), float((v2 - v).norm() / v.norm())), flush=True)
+    if ref is None: ref = v; continue
+    rel = float((v - ref).norm() / ref.norm())
+    if rel > 1e-4:
+        bad += 1
+        d = (v - ref).abs().view(-1, v.shape[-1])
+        if bad <= 3: print("iter", it, "rel %.3g" % rel, "pixels off:", int((d.max(dim=1).values > 1e-6 * float(ref.abs().max())).sum()), "of", d.shape[0],
+                           "channels off:", int((d.max(dim=0).values > 1e-6 * float(ref.abs().max())).sum()), flush=True)
+    worst = max(worst, rel)
+print(mode, "bad", bad, "worst %.3g" % worst, flush=True)

@@ -480,6 +480,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-output run of the whole CLI schedule")
     ap.add_argument("--no-families", action="store_true", help="skip the per-kernel-family HIP-event pass")
+    ap.add_argument("--halo", action="store_true", help="--mode strips: per-layer halo exchange instead of the recompute margin")
     ap.add_argument("--mode", choices=("replicas", "strips", "regions"), default="replicas",
                     help="N > 1: independent pairs per GPU (default, weak scaling); ONE pair sharded by image strips; or ONE "
                          "masked pair (BASELINE config 4) with its mask regions dealt to the ranks and one all-reduce of the "
@@ -515,7 +516,7 @@ def main():
     S = args.scale
     strips, regions, group = None, 1, None
     if args.mode == "strips" and world > 1:
-        strips = parallel.strip_plan(S, world, rank)
+        strips = parallel.strip_plan(S, world, rank, halo=args.halo)
         if strips is None:
             raise SystemExit(f"--mode strips: sharding a {S}-row image over {world} ranks does not pay (see strip_plan)")
     if args.mode == "regions":
@@ -552,7 +553,9 @@ def main():
     out = None
     if rank == 0:
         n_gpus = world
-        par_desc = ("one pair sharded by image strips (halo recompute), 2 all-reduces per step" if strips is not None else
+        par_desc = (("one pair sharded by image strips (per-layer halo exchange with the neighbouring ranks), 2 all-reduces per step"
+                     if strips.halo else "one pair sharded by image strips (halo recompute), 2 all-reduces per step")
+                    if strips is not None else
                     f"one masked pair, {regions} mask regions dealt round-robin to {n_gpus} rank(s), trunk replicated, "
                     f"1 all-reduce of the pixel gradient per step" if args.mode == "regions" else
                     "replicas (one pair per GPU)" if n_gpus > 1 else "single GPU")

@@ -159,6 +159,10 @@ typedef struct {
    * [row0[k], row0[k] + rows[k]) of a map whose full height is h[k]; coordinates and clipping stay those of
    * the full map (strotss_utils.py:43-64), the taps are then shifted into the window.  rows[k] == 0: whole map. */
   int row0[STROTSS_MAX_MAPS], rows[STROTSS_MAX_MAPS];
+  /* scatter (and its plan) only, windowed maps only: != 0 DROPS a tap whose row lies outside the window instead of
+   * clamping it to the window's edge -- halo-exchange strips: every rank scatters ALL samples and keeps what lands in
+   * the rows it holds.  The gather always clamps (a rank gathers its own samples, whose taps lie inside). */
+  int window_drop;
 } strotss_maps_t;
 /* out(rows, ld): row s < n = concat_k sample(map_k, idx[s]); bilinear != 0 -> 4-tap weights of
  * strotss_utils.py:43-70, else truncating nearest (72-75).  idx: (n,2) float32 (row, col). */

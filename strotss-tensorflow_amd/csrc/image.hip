@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void resize_adjoint_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------- hypercolumns
-struct SampleTap { int ia, ib, ic, id; float wa, wb, wc, wd; };
+struct SampleTap { int ia, ib, ic, id; float wa, wb, wc, wd; };   // (wa, wb: row x0; wc, wd: row x1)
 
 // strotss_utils.py:31-37 (cumulative float32 `indices /= y`) + 43-64 (floor / clip / 4 taps)
 __device__ __forceinline__ SampleTap sample_tap(const strotss_maps_t& m, int k, float gx, float gy,
@@ -144,8 +144,13 @@ __device__ __forceinline__ SampleTap sample_tap(const strotss_maps_t& m, int k, 
     const int y1 = min(y0 + 1, w - 1);
     int xa = x0;
     if (m.rows[k] > 0) {                            // window of a sharded map (clamped: never out of the buffer)
-      xa = min(max(x0 - m.row0[k], 0), m.rows[k] - 1);
-      x1 = min(max(x1 - m.row0[k], 0), m.rows[k] - 1);
+      const int ra = x0 - m.row0[k], rb = x1 - m.row0[k];
+      xa = min(max(ra, 0), m.rows[k] - 1);
+      x1 = min(max(rb, 0), m.rows[k] - 1);
+      if (m.window_drop) {                          // adjoint of a halo-exchange strip: rows outside take nothing
+        if (ra != xa) { t.wa = 0.f; t.wb = 0.f; }
+        if (rb != x1) { t.wc = 0.f; t.wd = 0.f; }
+      }
     }
     t.ia = xa * w + y0; t.ib = xa * w + y1; t.ic = x1 * w + y0; t.id = x1 * w + y1;
   } else {
@@ -383,7 +388,7 @@ int maps_ok(const strotss_maps_t* m) {
 
 extern "C" {
 
-int strotss_abi_version(void) { return 2; }
+int strotss_abi_version(void) { return 3; }
 const char* strotss_build_info(void) { return "libstrotss_hip gfx950 fp32-mfma " __DATE__ " " __TIME__; }
 
 int strotss_resize_bilinear(const float* in, int ih, int iw, int c, float* out, int oh, int ow, float alpha,

@@ -30,7 +30,8 @@ class MapsT(C.Structure):
                 ("div", C.c_float * MAX_DIVS),
                 ("map", C.c_void_p * MAX_MAPS),
                 ("gmap", C.c_void_p * MAX_MAPS),
-                ("row0", C.c_int * MAX_MAPS), ("rows", C.c_int * MAX_MAPS)]
+                ("row0", C.c_int * MAX_MAPS), ("rows", C.c_int * MAX_MAPS),
+                ("window_drop", C.c_int)]
 
 
 class TensorsT(C.Structure):
@@ -139,15 +140,17 @@ def require(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
 
 def make_maps(maps: Sequence[torch.Tensor], divs_per_map: Sequence[Sequence[float]],
               gmaps: Optional[Sequence[torch.Tensor]] = None,
-              windows: Optional[Sequence[Tuple[int, int]]] = None) -> MapsT:
+              windows: Optional[Sequence[Tuple[int, int]]] = None, window_drop: bool = False) -> MapsT:
     """maps: list of (1,h,w,c) or (h,w,c) tensors; divs_per_map[k]: the divisor chain for map k
     (each chain is a prefix of the longest one, as the reference's cumulative `indices /= y`).
     windows[k] = (row0, full_height): map k holds rows [row0, row0 + its height) of a map that is
-    `full_height` tall (spatially sharded trunk); None: whole maps."""
+    `full_height` tall (spatially sharded trunk); None: whole maps.  window_drop: the scatter drops taps whose row lies
+    outside the window instead of clamping them (halo-exchange strips)."""
     if len(maps) > MAX_MAPS:
         raise StrotssHipError("too many maps")
     m = MapsT()
     m.n_maps = len(maps)
+    m.window_drop = 1 if (window_drop and windows is not None) else 0
     longest = max(divs_per_map, key=len)
     if len(longest) > MAX_DIVS:
         raise StrotssHipError("divisor chain too long")

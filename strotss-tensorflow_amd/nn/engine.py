@@ -84,7 +84,9 @@ class StepEngine:
         win0, win1 = (strips.win0, strips.win1) if strips is not None else (0, h)
         if strips is not None:
             assert self.R == 1 and strips.h == h, "image strips: one region, plan made for this scale"
-        self.trunk = VGGTrunk(params, win1 - win0, w, with_grad=True)
+        # halo-exchange strips: the trunk refreshes its window's outermost rows from the neighbours after every layer
+        self._halo = parallel.HaloExchange(strips, dist_group) if (strips is not None and strips.halo) else None
+        self.trunk = VGGTrunk(params, win1 - win0, w, with_grad=True, halo=self._halo)
         # region sharding (masked runs): pixel gradient + the regions' scalars in ONE buffer = one all-reduce
         self.group = dist_group
         self.rank, self.world = parallel.world_info(dist_group) if dist_group is not None else (0, 1)
@@ -125,7 +127,8 @@ class StepEngine:
                 shift = (h // fh).bit_length() - 1 if fh < h else 0      # number of 2x2 pools above map k
                 assert win0 % (1 << shift) == 0 and (win0 >> shift) + int(m.shape[1]) <= fh
                 windows.append((win0 >> shift, fh))
-        self._mt_pred = _hip.make_maps(self.pred_maps, self.divs, gmaps, windows)
+        # (halo-exchange strips: the adjoint scatters ALL samples and drops the taps outside the window)
+        self._mt_pred = _hip.make_maps(self.pred_maps, self.divs, gmaps, windows, window_drop=self._halo is not None)
         self._mt_content = _hip.make_maps(self.content_feat, self.divs)
         self._layer_to_map = {li: k + 1 for k, li in enumerate(self.trunk.taps)}
         self._layer_to_map[-1] = 0
@@ -178,8 +181,10 @@ class StepEngine:
         k = self._layer_to_map[layer_index]
         for r in self.my_regions:
             idx, gp = self._idx[r], self.gp[r]
-            if self.strips is not None:           # this rank's block of samples only
+            if self.strips is not None and self._halo is None:   # this rank's block of samples only
                 idx, gp = idx[self._o0:self._o1], gp[self._o0:self._o1]
+            elif self.strips is not None:                        # halo exchange: every sample, taps outside the window dropped
+                idx, gp = idx[:self._n], gp[:self._n]
             if self.deterministic:
                 _ops.hypercol_scatter_sorted(self._mt_pred, self._plans[r], int(idx.shape[0]), gp, relu_mask_from=1,
                                              map_begin=k, map_end=k + 1)
@@ -192,7 +197,7 @@ class StepEngine:
         n_maps = len(self.pred_maps)
         for r in self.my_regions:
             idx, gp = self._idx[r], self.gp[r]
-            if self.strips is not None:
+            if self.strips is not None and self._halo is None:
                 idx, gp = idx[self._o0:self._o1], gp[self._o0:self._o1]
             if self.deterministic:
                 _ops.hypercol_scatter_sorted(self._mt_pred, self._plans[r], int(idx.shape[0]), gp, relu_mask_from=1,
@@ -271,6 +276,15 @@ class StepEngine:
     def _strip_stage_b(self) -> None:
         """losses on the assembled features (replicated), backward of this rank's rows through its window."""
         self._losses(0, self._n)
+        if self._halo is not None:
+            # every rank back-propagates (gradient crosses the strip borders through the exchanges, and every sample's
+            # taps that land in this window are scattered here); only the OWN rows of the pixel gradient are kept
+            if self.deterministic:
+                _ops.hypercol_scatter_plan(self._mt_pred, self._idx[0][:self._n], self._plans[0])
+            self.trunk.backward(self._scatter)
+            self.gimg_full[:, :self.strips.own0].zero_()
+            self.gimg_full[:, self.strips.own1:].zero_()
+            return
         if self.deterministic and self._o1 > self._o0:
             _ops.hypercol_scatter_plan(self._mt_pred, self._idx[0][self._o0:self._o1], self._plans[0])
         if self._o1 > self._o0:

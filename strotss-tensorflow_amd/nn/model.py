@@ -205,8 +205,11 @@ class VGGTrunk:
     gradient of that tap into `grads[layer_index]` (ReLU-masked); returns the pixel gradient buffer
     into which `scatter(-1)` has added the image-channel part."""
 
-    def __init__(self, params: VGGParams, h: int, w: int, with_grad: bool = True):
+    def __init__(self, params: VGGParams, h: int, w: int, with_grad: bool = True, halo=None):
+        """halo: a parallel.HaloExchange when (h, w) is the window of a halo-exchange strip: after every layer, forward
+        and backward, the window's outermost rows are refreshed from the neighbouring ranks."""
         self.p = params
+        self.halo = halo
         dev = params.device
         self.h, self.w = h, w
         self.acts: List[torch.Tensor] = []
@@ -229,6 +232,14 @@ class VGGTrunk:
                 self.plan.append(('conv', li, src))
                 src = ('conv', li)
                 li += 1
+        # pooling level (number of 2x2 pools above) of every layer's output and of every pooled map
+        self.layer_level, self.pool_level, lvl = {}, {}, 0
+        for step in self.plan:
+            if step[0] == 'pool':
+                lvl += 1
+                self.pool_level[step[1]] = lvl
+            else:
+                self.layer_level[step[1]] = lvl
         self.taps = params.tap_layer_indices
         self.with_grad = with_grad
         # Winograd tile per layer for this image size
@@ -242,7 +253,8 @@ class VGGTrunk:
             # gradient), the taps of all maps are scattered in ONE launch into zeroed buffers before the backward pass
             # and the producers accumulate -- 10 launches less per step at the 64 / 128 px scales.  The tapped layers'
             # gradient buffers are then slices of one allocation (one fill).
-            self.prescatter = self._can_prescatter() and os.environ.get("STROTSS_PRESCATTER", "1") != "0"
+            self.prescatter = (halo is None and self._can_prescatter()
+                               and os.environ.get("STROTSS_PRESCATTER", "1") != "0")
             if self.prescatter:
                 sizes = [a.numel() if i in set(self.taps) else 0 for i, a in enumerate(self.acts)]
                 self._tap_flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
@@ -291,7 +303,7 @@ class VGGTrunk:
                 elif self.wtile[li]:
                     nxt = self.plan[si + 1] if si + 1 < len(self.plan) else None
                     pool_out = pool_code = None
-                    if nxt is not None and nxt[0] == 'pool' and nxt[2] == li:     # the pool of this layer rides along
+                    if self.halo is None and nxt is not None and nxt[0] == 'pool' and nxt[2] == li:   # its pool rides along
                         pool_out = self.pools[nxt[1]]
                         pool_code = self.pool_codes[nxt[1]] if self.with_grad else None
                         pooled.add(nxt[1])
@@ -299,6 +311,8 @@ class VGGTrunk:
                                               pool_out=pool_out, pool_code=pool_code)
                 else:
                     _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
+                if self.halo is not None:     # (the pooling launch that may follow then reads right rows only)
+                    self.halo.refresh(self.acts[li], self.layer_level[li])
         return [self.acts[i] for i in self.taps]
 
     def backward(self, scatter: Callable[[int], None], scatter_all: Optional[Callable[[], None]] = None) -> torch.Tensor:
@@ -345,8 +359,12 @@ class VGGTrunk:
                             dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si])
                         if si in tapped:
                             scatter(si)
+                        if self.halo is not None:
+                            self.halo.refresh(self.grads[si], self.layer_level[si])
                     else:
                         dgrad(self.grads[li], wts, L["cin"], act_in=None, out=self.gpools[si])
+                        if self.halo is not None:
+                            self.halo.refresh(self.gpools[si], self.pool_level[si])
         return self.gimg
 
 

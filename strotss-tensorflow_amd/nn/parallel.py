@@ -110,6 +110,7 @@ def aggregate_throughput(units_per_rank: float, elapsed_local: float, group=None
 # ------------------------------------------------------------------ image strips
 STRIP_MARGIN = 128        # halo rows per side; receptive-field radius of block5_conv3 in image pixels is < 110
 STRIP_ALIGN = 16          # four 2x2 pools: windows start on multiples of 16 so every pooled grid stays aligned
+HALO_MARGIN = 16          # halo-EXCHANGE strips: one row of the deepest maps (1/16 resolution); 16 >> L rows at level L
 
 
 @dataclass(frozen=True)
@@ -122,6 +123,8 @@ class StripPlan:
     bounds: Tuple[int, ...]          # world + 1 strip boundaries, bounds[0] = 0, bounds[-1] = h
     win0: int
     win1: int
+    halo: bool = False               # True: margin = HALO_MARGIN and the window's outermost rows are refreshed from the
+                                     # neighbours after every layer (HaloExchange) instead of being recomputed from a 128-row margin
 
     @property
     def own0(self) -> int:
@@ -132,10 +135,14 @@ class StripPlan:
         return self.bounds[self.rank + 1]
 
 
-def strip_plan(h: int, world: int, rank: int, margin: int = STRIP_MARGIN, align: int = STRIP_ALIGN) -> Optional[StripPlan]:
-    """None when sharding does not pay: one rank, an empty strip, or windows that cover (almost) the whole image."""
+def strip_plan(h: int, world: int, rank: int, margin: int = STRIP_MARGIN, align: int = STRIP_ALIGN,
+               halo: bool = False) -> Optional[StripPlan]:
+    """None when sharding does not pay: one rank, an empty strip, or windows that cover (almost) the whole image.
+    halo=True: halo-exchange strips (margin = HALO_MARGIN; every strip at least 2 * HALO_MARGIN rows)."""
     if world <= 1:
         return None
+    if halo:
+        margin = HALO_MARGIN
     assert margin % align == 0
     bounds = [0] + [min(h, (r * h // world + align - 1) // align * align) for r in range(1, world)] + [h]
     if any(b1 <= b0 for b0, b1 in zip(bounds, bounds[1:])):
@@ -144,7 +151,63 @@ def strip_plan(h: int, world: int, rank: int, margin: int = STRIP_MARGIN, align:
     widest = max(min(h, bounds[r + 1] + margin) - max(0, bounds[r] - margin) for r in range(world))
     if widest * 4 > h * 3:            # less than 25 % of the trunk saved: replicate instead
         return None
-    return StripPlan(h, world, rank, tuple(bounds), win0, win1)
+    if halo and any(b1 - b0 < 2 * HALO_MARGIN for b0, b1 in zip(bounds, bounds[1:])):
+        return None                   # a strip must hold the rows it sends to both neighbours
+    return StripPlan(h, world, rank, tuple(bounds), win0, win1, halo)
+
+
+def halo_rows(plan: "StripPlan", n_rows: int, level: int) -> Tuple[int, int, int, int]:
+    """Row indices in a window tensor of `n_rows` rows at pooling level `level`:
+    (sent to the rank above, sent to the rank below, received from above, received from below)."""
+    m = HALO_MARGIN >> level
+    top = (plan.own0 - plan.win0) >> level
+    bottom = (plan.win1 - plan.own1) >> level
+    own = n_rows - top - bottom
+    assert m >= 1 and own >= m and top in (0, m) and bottom in (0, m), (level, n_rows, top, bottom)
+    return top + m - 1, top + own - m, 0, n_rows - 1
+
+
+class HaloExchange:
+    """Per-layer halo exchange of a strip-sharded trunk.  The window of rank r is its own rows +- HALO_MARGIN
+    image rows; at pooling level L that is m = HALO_MARGIN >> L rows of margin.  A 3x3 convolution (or its transpose) run
+    on the window with zero padding gets every row right except the OUTERMOST one on each interior side, whose true
+    neighbour lies outside the window; `refresh` replaces exactly that row with the neighbour's copy (for which it is an
+    own row, hence right) -- one row up and one row down per layer instead of recomputing a 128-row margin.
+    Point-to-point over RCCL (xGMI neighbours); under gloo, which has no GPU send/recv, the rows are staged through the host.
+    `level` = number of 2x2 pools above the tensor; tensors are (1, rows, w, c), rows = the window at that level."""
+
+    def __init__(self, plan: StripPlan, group=None):
+        import torch.distributed as dist
+        assert plan.halo
+        self.plan, self.group = plan, resolve_group(group)
+        self.rank, self.world = plan.rank, plan.world
+        self.up = self.rank - 1 if self.rank > 0 else None
+        self.down = self.rank + 1 if self.rank + 1 < self.world else None
+        self._stage = dist.get_backend(self.group) == "gloo"
+        self.messages = 0
+
+    def refresh(self, t: torch.Tensor, level: int) -> None:
+        import torch.distributed as dist
+        if self.up is None and self.down is None:
+            return
+        su, sd, ru, rd = halo_rows(self.plan, int(t.shape[1]), level)
+        ops, recvs = [], []
+        for peer, s_row, r_row in ((self.up, su, ru), (self.down, sd, rd)):
+            if peer is None:
+                continue
+            src, dst = t[0, s_row], t[0, r_row]
+            if self._stage:
+                src = src.cpu()
+                buf = torch.empty_like(src)
+                recvs.append((dst, buf))
+                dst = buf
+            ops.append(dist.P2POp(dist.isend, src, peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, dst, peer, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for dst, buf in recvs:
+            dst.copy_(buf)
+        self.messages += len(ops) // 2
 
 
 def sort_indices_by_strip(idx: np.ndarray, plan: StripPlan) -> Tuple[np.ndarray, List[int]]:

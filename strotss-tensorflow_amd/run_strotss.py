@@ -169,7 +169,7 @@ def run(args: argparse.Namespace, trace=None):
         scl_content, scl_style = utils.resize(content, scl), utils.resize(style, scl)
         stylized, lr = _initial_image(position, position > 0 and i == level - 1, stylized, scl_content, scl_style,
                                       args.lr)
-        plan = (parallel.strip_plan(int(scl_content.shape[1]), world, rank)
+        plan = (parallel.strip_plan(int(scl_content.shape[1]), world, rank, halo=bool(getattr(args, "halo", False)))
                 if world > 1 and not masked and getattr(args, "strips", False) else None)
         eng = strotss_engine.StepEngine(
             vgg.params, strotss_engine.extract_features(vgg.params, scl_content),
@@ -210,6 +210,8 @@ _FLAGS = (
     (("--weights",), dict(type=str, default=None)), (("--log_every",), dict(type=int, default=10)),
     (("--no_graph",), dict(action='store_true', help="eager kernel launches instead of one hipGraph per step")),
     (("--strips",), dict(action='store_true', help="under torchrun: shard ONE image over the GPUs by image strips")),
+    (("--halo",), dict(action='store_true', help="with --strips: per-layer halo EXCHANGE with the neighbouring ranks (16-row "
+                                                 "windows margins, one row per layer and direction) instead of a 128-row recompute margin")),
 )
 
 

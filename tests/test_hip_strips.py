@@ -163,7 +163,8 @@ def test_strip_margin_must_cover_the_receptive_field():
     assert parallel.STRIP_MARGIN >= 112 and parallel.STRIP_MARGIN % parallel.STRIP_ALIGN == 0
 
 
-def test_cli_strips_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("halo", [False, True], ids=["recompute", "halo_exchange"])
+def test_cli_strips_two_ranks_on_one_gpu(tmp_path, halo):
     """The real sharded path with real collectives: two processes (both on this box's single GPU, gloo instead of
     RCCL, which refuses two ranks on one device) run `run_strotss.py --strips` on the 512-px scale; their output must
     match the single-process run of the same command up to the rounding noise RMSprop's sign-like first steps amplify."""
@@ -184,9 +185,9 @@ def test_cli_strips_two_ranks_on_one_gpu(tmp_path):
     assert one.returncode == 0, one.stderr[-2000:]
     procs = []
     for rank in range(2):
-        e = dict(env, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+        e = dict(env, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29542" if halo else "29541",
                  STROTSS_DIST_BACKEND="gloo")
-        procs.append(subprocess.Popen(base + ["--strips", "-o", str(tmp_path / f"two{rank}.jpg")], env=e,
+        procs.append(subprocess.Popen(base + ["--strips"] + (["--halo"] if halo else []) + ["-o", str(tmp_path / f"two{rank}.jpg")], env=e,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
@@ -204,3 +205,52 @@ def test_cli_strips_two_ranks_on_one_gpu(tmp_path):
     import re
     losses = [re.findall(r"loss=([0-9.]+), loss_c=([0-9.]+), loss_s=([0-9.]+)", t)[-1] for t in (one.stderr, outs[0][1])]
     assert losses[0] == losses[1], losses
+
+
+def _halo_two_ranks(tmp_path, h):
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), STROTSS_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "_halo_worker.py"), str(tmp_path / "out"), str(h)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    return [torch.load(f"{tmp_path / 'out'}.r{r}.pt") for r in range(2)]
+
+
+def test_halo_exchange_strips_two_ranks_equal_the_unsharded_step(tmp_path):
+    """Per-layer halo EXCHANGE (SURVEY 8f-1 as written; nn/parallel.py HaloExchange): two real processes, 16-row window
+    margins, after every layer -- forward and backward -- one row up and one row down between the neighbours (gloo on the
+    one GPU of this box, rows staged through the host).  The step must equal the unsharded engine's: same sampled rows,
+    losses to 2e-5, every variable's gradient to 3e-3 relative L2 (window shapes change the Winograd tiling, as in the
+    recompute test), identical variables on both ranks after three steps."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _halo_worker as W
+    h = 128
+    eng, idx = W.problem(torch.device("cuda", 0), None, h=h)
+    ref = W.run(eng, idx, None)
+    r0, r1 = _halo_two_ranks(tmp_path, h)
+    assert r0["window"] == (0, 80, 0, 64) and r1["window"] == (48, 128, 64, 128)
+    # 13 conv layers forward + 12 data-gradients (+ 4 pooled-gradient maps) backward, one message each way, 3 steps
+    assert r0["messages"] == r1["messages"] and r0["messages"] >= 3 * 25
+    from nn import parallel
+    order = np.argsort(np.searchsorted(np.asarray([64]), idx[0][:, 0], side="right"), kind="stable")
+    n = idx[0].shape[0]
+    assert float((r0["pf0"][:n] - ref["pf0"][order]).abs().max()) < 2e-4 * float(ref["pf0"].abs().max())
+    assert torch.equal(r0["pf0"], r1["pf0"])
+    for k in ("loss", "loss_c", "loss_s"):
+        assert abs(r0["losses0"][k] - ref["losses0"][k]) < 2e-5 * max(1.0, abs(ref["losses0"][k])), (k, r0["losses0"], ref["losses0"])
+        assert r0["losses0"][k] == r1["losses0"][k]
+    for a, b, c in zip(ref["gvars0"], r0["gvars0"], r1["gvars0"]):
+        assert torch.equal(b, c)
+        rel = float((a - b).norm() / a.norm())
+        assert rel < 3e-3, rel
+    for b, c in zip(r0["variables"], r1["variables"]):
+        assert torch.equal(b, c)
+    assert abs(r0["losses2"]["loss"] - ref["losses2"]["loss"]) < 2e-2 * abs(ref["losses2"]["loss"])

@@ -145,3 +145,28 @@ def test_bench_gpus_flag_starts_the_ranks():
 def test_bench_refuses_a_world_size_mismatch():
     out, lines = _bench(["--gpus", "4", "--rehearse"], env_extra={"WORLD_SIZE": "1", "RANK": "0"}, drop=())
     assert out.returncode != 0 and not lines and "--gpus 4 but WORLD_SIZE=1" in out.stderr
+
+
+def test_halo_exchange_geometry_matches_between_neighbours():
+    """nn/parallel.py halo_rows (per-layer halo exchange of strip-sharded trunks): at every pooling level the
+    row a rank sends down is the image-level row its lower neighbour receives from above, and vice versa; the received
+    rows are the outermost rows of the window and the sent rows are OWN rows of the sender."""
+    from nn import parallel as P
+    for h, world in ((1024, 2), (1024, 4), (1024, 8), (512, 4), (128, 2), (640, 3), (601, 2)):
+        plans = [P.strip_plan(h, world, r, halo=True) for r in range(world)]
+        assert all(p is not None and p.halo for p in plans), (h, world)
+        for p in plans:
+            assert p.win0 == max(0, p.own0 - P.HALO_MARGIN) and p.win1 == min(h, p.own1 + P.HALO_MARGIN)
+        for level in range(5):
+            geo = []
+            for p in plans:
+                n = (p.win1 - p.win0) >> level                      # rows of the window tensor at this level (floor, as the pools)
+                su, sd, ru, rd = P.halo_rows(p, n, level)
+                base = p.win0 >> level
+                geo.append((base + su, base + sd, base + ru, base + rd, p.own0 >> level, p.own1 >> level))
+            for up, down in zip(geo, geo[1:]):
+                assert up[1] == down[2], (h, world, level)           # sent down by the upper rank == received from above
+                assert down[0] == up[3], (h, world, level)           # sent up by the lower rank == received from below
+                assert up[4] <= up[1] < up[5] and down[4] <= down[0] < down[5]   # senders send rows they own
+    # too-thin strips: no plan (a strip must hold the rows it sends to both neighbours)
+    assert P.strip_plan(64, 4, 0, halo=True) is None

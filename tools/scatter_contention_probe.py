@@ -44,6 +44,10 @@ for it in range(int(sys.argv[1])):
     if rel > 1e-4:
         bad += 1
         d = (v - ref).abs().view(-1, v.shape[-1])
+        if bad <= 6: print("iter", it, "sum(wrong) - sum(ref) = %.4g of sum|ref| %.4g; |wrong|^2/|ref|^2 = %.5f;" % (
+                           float(v.double().sum() - ref.double().sum()), float(ref.double().abs().sum()),
+                           float((v.double() ** 2).sum() / (ref.double() ** 2).sum())),
+                           "largest |diff| / max|ref| %.3g" % float((v - ref).abs().max() / ref.abs().max()), flush=True)
         if bad <= 3: print("iter", it, "rel %.3g" % rel, "pixels off:", int((d.max(dim=1).values > 1e-6 * float(ref.abs().max())).sum()), "of", d.shape[0],
                            "channels off:", int((d.max(dim=0).values > 1e-6 * float(ref.abs().max())).sum()), flush=True)
     worst = max(worst, rel)

@@ -7,7 +7,8 @@ steps on the same GPU (start this script twice): about one launch in ten is off 
 whole cache lines, although its inputs are bitwise unchanged and every launch is bracketed by device synchronisations.
 tools/atomic_probe.hip (plain float atomics with the same address patterns and lane masks) stays exact under the same
 contention, system-scope atomics change nothing, and the sorted scatter (STROTSS_DETERMINISTIC=1) stays bitwise equal.
-Cause not found; DESIGN.md 6 has the record.  Usage: python tools/scatter_contention_probe.py ITERATIONS [all|one|nomask]"""
+That was the library as built up to commit 99e99cc; the current build (one more field in strotss_maps_t, same kernel source)
+has not shown it in ~2000 launches.  Cause not found; DESIGN.md 6 has the record.  Usage: python tools/scatter_contention_probe.py ITERATIONS [all|one|nomask]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "strotss-tensorflow_amd"), os.path.join(ROOT, "tests")):

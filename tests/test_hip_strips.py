@@ -254,3 +254,23 @@ def test_halo_exchange_strips_two_ranks_equal_the_unsharded_step(tmp_path):
     for b, c in zip(r0["variables"], r1["variables"]):
         assert torch.equal(b, c)
     assert abs(r0["losses2"]["loss"] - ref["losses2"]["loss"]) < 2e-2 * abs(ref["losses2"]["loss"])
+
+
+@pytest.mark.parametrize("halo", [False, True], ids=["recompute", "halo_exchange"])
+def test_bench_strips_mode_two_ranks_prints_one_line(halo):
+    """`python bench.py --gpus 2 --mode strips [--halo]` with no torchrun around it starts its two ranks itself (gloo
+    rehearsal on the one GPU) and rank 0 prints ONE JSON line: n_gpus 2, strong scaling, the sharding named in `config`."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["STROTSS_DIST_BACKEND"] = "gloo"
+    env["STROTSS_DETERMINISTIC"] = "1"           # two processes on one GPU (DESIGN.md 6)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "strips", "--scale", "512",
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-pyramid", "--no-families"]
+                         + (["--halo"] if halo else []), env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["launch_mode"] == "eager"
+    assert ("halo exchange" in line["config"]["parallelism"]) == halo and "strips" in line["config"]["parallelism"]

@@ -289,6 +289,52 @@ def test_hypercol_gather_and_scatter(ops, hw):
         assert np.abs(a.cpu().numpy() - ref_g).max() < 1e-5 * max(1.0, np.abs(ref_g).max()), k
 
 
+@pytest.mark.parametrize("sorted_scatter", [False, True], ids=["atomic", "sorted"])
+def test_hypercol_scatter_window_drop(ops, sorted_scatter):
+    """Windowed maps (spatially sharded trunk, `strotss_maps_t.row0/rows`): with `window_drop` the adjoint of ALL samples keeps
+    exactly what lands in the rows a window holds (halo-exchange strips, nn/parallel.py) -- it must equal the same rows of the
+    full-map adjoint; without it (recompute strips) out-of-window taps are clamped onto the window's edge rows."""
+    from nn import _hip
+    h, w = 64, 48
+    maps = _maps(h, w, 3)
+    rng = np.random.default_rng(9)
+    idx = O.make_indices(h, w, True, 300, rng)
+    dmaps = [dev(m) for m in maps]
+    d = sum(m.shape[-1] for m in maps)
+    gbuf = torch.zeros(ops.pad32(len(idx)), ops.pad32(d), device="cuda")
+    gbuf[:len(idx), :d] = dev(torch.randn(len(idx), d, generator=torch.Generator().manual_seed(4), dtype=torch.float64))
+    divs = ops.map_divisors([ops.hwc(m)[:2] for m in dmaps])
+    full = [torch.zeros_like(m) for m in dmaps]
+    ops.hypercol_scatter(dmaps, full, dev(idx), gbuf, relu_mask_from=1)
+    # window = image rows [16, 48): rows [16 >> L, 48 >> L) of the maps at pooling level L
+    wins, wmaps = [], []
+    for m in dmaps:
+        lvl = (h // m.shape[1]).bit_length() - 1
+        r0, r1 = 16 >> lvl, 48 >> lvl
+        wins.append((r0, int(m.shape[1])))
+        wmaps.append(m[:, r0:r1].contiguous())
+    for drop in (True, False):
+        gw = [torch.zeros_like(m) for m in wmaps]
+        mt = _hip.make_maps(wmaps, divs, gw, wins, window_drop=drop)
+        assert mt.window_drop == int(drop)
+        if sorted_scatter:
+            plan = ops.hypercol_scatter_plan(mt, dev(idx))
+            ops.hypercol_scatter_sorted(mt, plan, len(idx), gbuf, relu_mask_from=1)
+        else:
+            ops.hypercol_scatter(wmaps, None, dev(idx), gbuf, relu_mask_from=1, maps_t=mt)
+        torch.cuda.synchronize()
+        for k, (g_, f, (r0, _)) in enumerate(zip(gw, full, wins)):
+            ref = f[:, r0:r0 + g_.shape[1]]
+            err = float((g_ - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+            if drop:
+                assert err < 1e-5, (k, err)
+            else:
+                interior = float((g_[:, 1:-1] - ref[:, 1:-1]).abs().max()) / max(1.0, float(ref.abs().max()))
+                assert interior < 1e-5, (k, interior)              # clamping only ever touches the two edge rows ...
+        if not drop:
+            assert any(float((g_ - f[:, r0:r0 + g_.shape[1]]).abs().max()) > 1e-3 for g_, f, (r0, _) in zip(gw, full, wins))   # ... and does
+
+
 # ------------------------------------------------------------------ losses
 @pytest.mark.parametrize("n,d", [(48, 35), (200, 131), (64, 64), (1024, 259), (70, 20), (129, 96), (6, 7)])
 def test_cosine_distance_and_norms(ops, n, d):

@@ -487,20 +487,44 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* _
   const int trips = H * segs_x;
   const float b0 = bias[l31], b1 = bias[32 + l31];
   float* st = stage + wave * (32 * C3F_RS);
+  // The patch of trip t+1 is fetched into registers while trip t computes: its HBM latency hides behind the MFMAs and the
+  // output stores instead of standing between two barriers.  Which patch element a thread stages (row, pixel, channel,
+  // its mean and 1/std) does not depend on the trip: worked out once, so a trip costs a thread two adds, the bounds
+  // test and one multiply-add per element (the f32 MFMA blocks the vector issue: every instruction here is MFMA time).
+  constexpr int NPF = (3 * C3F_PW * 3 + 255) / 256;    // patch elements per thread
+  int prow[NPF], poff[NPF];
+  float pm[NPF], pis[NPF], pv[NPF];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int r = e / (C3F_PW * 3), rem = e - r * (C3F_PW * 3);
+    const int px = rem / 3, ch = rem - px * 3;
+    prow[i] = e < 3 * C3F_PW * 3 ? r - 1 : -(1 << 20);                  // (past the patch: never inside the image)
+    poff[i] = (px - 1) * 3 + ch;                                        // float offset from pixel x0 of row y + r - 1
+    pm[i] = ch == 0 ? mean_[0] : (ch == 1 ? mean_[1] : mean_[2]);
+    pis[i] = ch == 0 ? istd_[0] : (ch == 1 ? istd_[1] : istd_[2]);
+  }
+  auto inside = [&](int i, int y, int x0) {
+    const int yy = y + prow[i], x3 = x0 * 3 + poff[i];
+    return yy >= 0 && yy < H && x3 >= 0 && x3 < W * 3;
+  };
+  auto fetch = [&](int trip) {                         // loads only: nothing here waits for them
+    const int y = trip / segs_x, x0 = (trip - y * segs_x) * C3F_SEG;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i)
+      pv[i] = img[inside(i, y, x0) ? (size_t)(y + prow[i]) * W * 3 + x0 * 3 + poff[i] : 0];
+  };
+  if ((int)blockIdx.x < trips) fetch(blockIdx.x);
   for (int trip = blockIdx.x; trip < trips; trip += gridDim.x) {
     const int y = trip / segs_x, x0 = (trip - y * segs_x) * C3F_SEG;
     __syncthreads();                                   // the previous trip's A reads are done (first trip: wsm visible)
-    for (int e = threadIdx.x; e < 3 * C3F_PW * 3; e += 256) {
-      const int r = e / (C3F_PW * 3), rem = e - r * (C3F_PW * 3);
-      const int px = rem / 3, ch = rem - px * 3;
-      const int yy = y + r - 1, xx = x0 + px - 1;
-      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const float v = img[ok ? ((size_t)yy * W + xx) * 3 + ch : 0];
-      const float m = ch == 0 ? mean_[0] : (ch == 1 ? mean_[1] : mean_[2]);
-      const float is = ch == 0 ? istd_[0] : (ch == 1 ? istd_[1] : istd_[2]);
-      patch[e] = ok ? (v - m) * is : 0.f;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      if (e < 3 * C3F_PW * 3) patch[e] = inside(i, y, x0) ? (pv[i] - pm[i]) * pis[i] : 0.f;
     }
     __syncthreads();
+    if (trip + (int)gridDim.x < trips) fetch(trip + gridDim.x);
     const int xw = x0 + wave * 32;                     // this wave's 32 pixels
     if (xw >= W) continue;
     f32x16 acc0, acc1;

@@ -674,28 +674,45 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
   }
 }
 // backward from the forward pass's argmax codes: reads gout + 1 byte per pooled element instead of the activations
+// One thread per POOLED element (4 channels): code word and gradient are read once and the 2 x 2 window is written from
+// registers; one workgroup row per pooled row, 32-bit index arithmetic (the element-per-thread form spent its time in
+// four 64-bit divisions per element and fetched every pooled value four times).  An odd last row / column of the input
+// lies outside every window: it gets zeros (blockIdx.y == Ho, ox == Wo).
 __global__ __launch_bounds__(256) void maxpool2_bwd_code_kernel(const unsigned* __restrict__ code, int H, int W, int C4,
                                                                 const float* __restrict__ gout,
                                                                 float* __restrict__ gin, int accumulate) {
   const int Ho = H >> 1, Wo = W >> 1;
-  const size_t total = (size_t)H * W * C4;
+  const int Wx = Wo + (W & 1);                                  // pooled columns + the odd column, if any
+  const int row_elems = Wx * C4;
   const f32x4* g = reinterpret_cast<const f32x4*>(gout);
   f32x4* dst = reinterpret_cast<f32x4*>(gin);
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int c = (int)(e % C4);
-    const size_t pix = e / C4;
-    const int x = (int)(pix % W), y = (int)(pix / W);
-    const int oy = y >> 1, ox = x >> 1;
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (oy < Ho && ox < Wo) {
-      const size_t po = ((size_t)oy * Wo + ox) * C4 + c;
-      const unsigned me = (unsigned)(((y & 1) << 1) | (x & 1));
-      const unsigned cd = code[po];
-      const f32x4 go = g[po];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int oy = blockIdx.y; oy < Ho + (H & 1); oy += gridDim.y) {
+    const bool pooled_row = oy < Ho;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < row_elems; e += gridDim.x * 256) {
+      const int ox = e / C4, c = e - ox * C4;
+      const bool pooled = pooled_row && ox < Wo;
+      f32x4 r[4] = {z, z, z, z};
+      if (pooled) {
+        const size_t po = ((size_t)oy * Wo + ox) * C4 + c;
+        const unsigned cd = code[po];
+        const f32x4 go = g[po];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) r[k] = (((cd >> (8 * k)) & 0xffu) == me) ? go[k] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+          const unsigned me = (cd >> (8 * k)) & 0xffu;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r[q][k] = me == (unsigned)q ? go[k] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                              // q = (dy << 1) | dx
+        const int y = 2 * oy + (q >> 1), x = 2 * ox + (q & 1);
+        if (y < H && x < W) {
+          const size_t o = ((size_t)y * W + x) * C4 + c;
+          dst[o] = accumulate ? dst[o] + r[q] : r[q];
+        }
+      }
     }
-    dst[e] = accumulate ? dst[e] + r : r;
   }
 }
 // gin[y,x,c] = (this pixel is the FIRST max of its window, scan order (0,0),(0,1),(1,0),(1,1))
@@ -818,9 +835,12 @@ int strotss_maxpool2_bwd(const float* act, int h, int w, int c, const float* gou
   ST_CHECK_ARG(c % 4 == 0, STROTSS_EALIGN);
   const size_t total = (size_t)h * w * (c / 4);
   const dim3 grid((unsigned)min((size_t)8192, (total + 255) / 256));
-  if (code)
-    hipLaunchKernelGGL(maxpool2_bwd_code_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+  if (code) {
+    const int row_elems = ((w >> 1) + (w & 1)) * (c / 4), rows = (h >> 1) + (h & 1);
+    const dim3 g2((unsigned)min(64, cdiv(row_elems, 256)), (unsigned)min(rows, 16384));
+    hipLaunchKernelGGL(maxpool2_bwd_code_kernel, g2, dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned*>(code), h, w, c / 4, gout, gin, accumulate);
+  }
   else
     hipLaunchKernelGGL(maxpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, act, h, w, c / 4, gout, gin, accumulate);
   ST_LAUNCH_RET();

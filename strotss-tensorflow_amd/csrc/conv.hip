@@ -644,13 +644,14 @@ __global__ __launch_bounds__(512) void conv3x3_c3_dgrad_lds_kernel(const float* 
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ in, int H, int W, int C4,
                                                            float* __restrict__ out, unsigned* __restrict__ code) {
   const int Ho = H >> 1, Wo = W >> 1;
-  const size_t total = (size_t)Ho * Wo * C4;
+  const int row_elems = Wo * C4;
   const f32x4* src = reinterpret_cast<const f32x4*>(in);
   f32x4* dst = reinterpret_cast<f32x4*>(out);
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int c = (int)(e % C4);
-    const size_t pix = e / C4;
-    const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+  // one workgroup row per pooled row, 32-bit index arithmetic (no 64-bit division per element)
+  for (int oy = blockIdx.y; oy < Ho; oy += gridDim.y)
+  for (int er = blockIdx.x * 256 + threadIdx.x; er < row_elems; er += gridDim.x * 256) {
+    const int ox = er / C4, c = er - ox * C4;
+    const size_t e = (size_t)oy * row_elems + er;
     const size_t b = ((size_t)(2 * oy) * W + 2 * ox) * C4 + c;
     const f32x4 v00 = src[b], v01 = src[b + C4], v10 = src[b + (size_t)W * C4], v11 = src[b + (size_t)W * C4 + C4];
     f32x4 m;
@@ -823,8 +824,8 @@ extern "C" {
 int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, void* stream) {
   ST_CHECK_ARG(in && out && h >= 2 && w >= 2 && c > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(c % 4 == 0, STROTSS_EALIGN);
-  const size_t total = (size_t)(h / 2) * (w / 2) * (c / 4);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(min((size_t)8192, (total + 255) / 256)), dim3(256), 0,
+  const dim3 grid((unsigned)min(64, cdiv((w / 2) * (c / 4), 256)), (unsigned)min(h / 2, 16384));
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, grid, dim3(256), 0,
                      (hipStream_t)stream, in, h, w, c / 4, out, reinterpret_cast<unsigned*>(code));
   ST_LAUNCH_RET();
 }

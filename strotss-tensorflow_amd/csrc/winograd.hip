@@ -129,17 +129,25 @@ __device__ __forceinline__ void bt6(f32x4 (&d)[6]) {       // in-place B^T d
   d[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
   d[5] = 4.f * d1 - 5.f * d3 + d5;
 }
+// Element index -> (tile, channel quad) in 32-bit arithmetic (a shift when C4 is a power of two, as in VGG): the 64-bit
+// `%` / `/` these transforms used to do four times per thread cost more instructions than the transform itself.
+__device__ __forceinline__ void split_index(unsigned e, int C4, int c4_shift, unsigned& tile, int& c) {
+  if (c4_shift >= 0) { tile = e >> c4_shift; c = (int)(e & (unsigned)(C4 - 1)); }
+  else { tile = e / (unsigned)C4; c = (int)(e - tile * (unsigned)C4); }
+}
+static int log2_or_minus1(int v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctz((unsigned)v) : -1; }
+
 // V: (36, T, C), T = ceil(H/4)*ceil(W/4); tile (ty,tx) reads input rows 4ty-1..4ty+4, cols 4tx-1..4tx+4
 __global__ __launch_bounds__(256) void winograd43_in_kernel(const float* __restrict__ in, int H, int W, int C4,
-                                                            int TH, int TW, float* __restrict__ V) {
+                                                            int TH, int TW, float* __restrict__ V, int c4_shift) {
   const size_t T = (size_t)TH * TW;
-  const size_t total = T * C4;
+  const unsigned total = (unsigned)(T * C4);
   const f32x4* src = reinterpret_cast<const f32x4*>(in);
   f32x4* dst = reinterpret_cast<f32x4*>(V);
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int c = (int)(e % C4);
-    const size_t tile = e / C4;
-    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+    unsigned tile; int c;
+    split_index(e, C4, c4_shift, tile, c);
+    const int ty = (int)(tile / (unsigned)TW), tx = (int)(tile - (unsigned)ty * (unsigned)TW);
     f32x4 d[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -172,20 +180,20 @@ __global__ __launch_bounds__(256) void winograd43_in_kernel(const float* __restr
 // T rows x C columns.  Lane order: 8 lanes = the 32 channels of one K-block of one tile (128 B read per pixel),
 // 8 consecutive tiles per wave: 512 contiguous bytes per plane, position and wave store.
 __global__ __launch_bounds__(256) void winograd43_in_x3_kernel(const float* __restrict__ in, int H, int W, int C4,
-                                                               int TH, int TW, __bf16* __restrict__ V) {
+                                                               int TH, int TW, __bf16* __restrict__ V, int kb_shift) {
   const size_t T = (size_t)TH * TW;
   const int KB = C4 >> 3;
-  const size_t total = ((T + 7) >> 3) * 64 * KB;
+  const unsigned total = (unsigned)(((T + 7) >> 3) * 64 * KB);
   const f32x4* src = reinterpret_cast<const f32x4*>(in);
   const size_t panel = 3 * T * (size_t)C4 * 4;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
     const int c8 = (int)(e & 7), tlo = (int)((e >> 3) & 7);
-    const size_t r = e >> 6;
-    const int kb = (int)(r % KB);
-    const size_t tile = (r / KB) * 8 + tlo;
+    unsigned r8; int kb;
+    split_index(e >> 6, KB, kb_shift, r8, kb);
+    const unsigned tile = r8 * 8 + tlo;
     if (tile >= T) continue;
     const int c = kb * 8 + c8;
-    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+    const int ty = (int)(tile / (unsigned)TW), tx = (int)(tile - (unsigned)ty * (unsigned)TW);
     f32x4 d[6][6];
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr) {
@@ -218,16 +226,16 @@ __global__ __launch_bounds__(256) void winograd43_in_x3_kernel(const float* __re
 __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __restrict__ Mw, int H, int W, int C4,
                                                              int TH, int TW, const float* __restrict__ bias,
                                                              const float* __restrict__ mask, int relu,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int c4_shift) {
   const size_t T = (size_t)TH * TW;
-  const size_t total = T * C4;
+  const unsigned total = (unsigned)(T * C4);
   const f32x4* src = reinterpret_cast<const f32x4*>(Mw);
   const f32x4* msk = reinterpret_cast<const f32x4*>(mask);
   f32x4* dst = reinterpret_cast<f32x4*>(out);
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int c = (int)(e % C4);
-    const size_t tile = e / C4;
-    const int tx = (int)(tile % TW), ty = (int)(tile / TW);
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+    unsigned tile; int c;
+    split_index(e, C4, c4_shift, tile, c);
+    const int ty = (int)(tile / (unsigned)TW), tx = (int)(tile - (unsigned)ty * (unsigned)TW);
     f32x4 s[4][6];                       // s = A^T M   (rows of A^T applied down the columns of M)
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -318,6 +326,7 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const size_t T = (size_t)TH * TW;
   const bool x3 = Ux3 && cin % 32 == 0 && x3_enabled(T, cout);
+  if (T * (size_t)(max(cin, cout) / 4 + 8) >= (1ull << 32)) return STROTSS_ERANGE;     // 32-bit element indices in the transforms
   Workspace ws(workspace, workspace_bytes);
   float* V = ws.take<float>(36 * T * cin * 3 / 2);           // f32 V, or its x3 panels (3 bf16 per value)
   float* Mw = ws.take<float>(36 * T * cout);
@@ -327,18 +336,18 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
   if (x3) {
     const size_t tin = ((T + 7) / 8) * 8 * (cin / 4);
     hipLaunchKernelGGL(winograd43_in_x3_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
-                       in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V));
+                       in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V), log2_or_minus1(cin / 32));
     rc = st_gemm_x3_batched(V, Ux3, Mw, cout, (long long)T * cout, (int)T, cout, cin, 36, st, x3_min_tiles());
   } else {
     const size_t tin = T * (cin / 4);
     hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
-                       h, w, cin / 4, TH, TW, V);
+                       h, w, cin / 4, TH, TW, V, log2_or_minus1(cin / 4));
     rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
                             (long long)T * cout, (int)T, cout, cin, 36, st);
   }
   if (rc != 0) return rc;
   hipLaunchKernelGGL(winograd43_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
-                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out);
+                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out, log2_or_minus1(cout / 4));
   ST_LAUNCH_RET();
 }
 

@@ -240,6 +240,16 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
 int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld,
                                  int rgb_to_yuv, float gscale, float* gpred, float* loss_out,
                                  void* workspace, size_t workspace_bytes, void* stream);
+/* relaxed_emd(style, pred, distance) for the other two entries of dist_metrics (losses.py:27-28) at ANY width d:
+ * metric STROTSS_METRIC_L2 -> l2_distance (losses.py:18-24), STROTSS_METRIC_BOTH -> cosine + l2.  Same reductions and
+ * tie rules as strotss_remd_cos_fwd_bwd (tf.reduce_min splits among ties, tf.maximum -> first argument);
+ * tf.maximum(m, 1e-6) inside l2_distance passes gradient where m >= 1e-6.  gpred += gscale*dloss/dpred. */
+#define STROTSS_METRIC_L2 1
+#define STROTSS_METRIC_BOTH 2
+size_t strotss_remd_metric_workspace_bytes(int ns, int n);
+int strotss_remd_metric_fwd_bwd(const float* style, int ns, const float* pred, int n, int d, int ld, int metric,
+                                float gscale, float* gpred, float* loss_out, void* workspace,
+                                size_t workspace_bytes, void* stream);
 size_t strotss_moment_workspace_bytes(int n, int ld);
 /* style side of moment_matching, once per scale: mean_out(ld), cov_out(ld,ld) = biased covariance */
 int strotss_moment_stats(const float* x, int n, int d, int ld, float* mean_out, float* cov_out,

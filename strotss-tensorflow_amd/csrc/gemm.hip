@@ -61,10 +61,29 @@ struct EpiCosDistX3 : EpiCosDist, X3NoPrefetch<EpiCosDistX3> {
 };
 struct EpiL2Dist {  // C = sqrt(max(xs[i] + ys[j] - 2 acc, 1e-6) / D)      (losses.py:18-24)
   static constexpr bool SYMM = false;
-  const float* xs; const float* ys; float* C; int ldc; int M, N; float inv_d;
+  const float* xs; const float* ys; float* C; int ldc; int M, N; float d;
   __device__ __forceinline__ void set_batch(int) {}
   __device__ __forceinline__ float apply(int r, int c, float v) const {
-    if (r < M && c < N) C[(size_t)r * ldc + c] = sqrtf(fmaxf(xs[r] + ys[c] - 2.0f * v, 1e-06f) * inv_d);
+    if (r < M && c < N) C[(size_t)r * ldc + c] = sqrtf(fmaxf(xs[r] + ys[c] - 2.0f * v, 1e-06f) / d);
+    return 0.f;
+  }
+  __device__ __forceinline__ void finish(float*, float) const {}
+};
+// relaxed_emd cost for dist_metrics 'l2' / 'both' (losses.py:18-28) at any width, from ONE product: the l2 distance
+// (metric 1) or cosine + l2 (metric 2) in C, and the l2 part alone in S with its sign telling whether tf.maximum(m, 1e-6)
+// passes gradient to m (m >= 1e-6: +l2) or not (-l2) -- the backward kernel needs the l2 term of its selected entries.
+struct EpiRemdCost {
+  static constexpr bool SYMM = false;
+  const float* ra; const float* rb; const float* sa; const float* sb; float* C; float* S; int ldc; int M, N; float d; int metric;
+  __device__ __forceinline__ void set_batch(int) {}
+  __device__ __forceinline__ float apply(int r, int c, float v) const {
+    if (r < M && c < N) {
+      const float m = sa[r] + sb[c] - 2.0f * v;
+      const float l2 = sqrtf(fmaxf(m, 1e-06f) / d);
+      const size_t o = (size_t)r * ldc + c;
+      C[o] = metric == 1 ? l2 : (1.0f - v * (ra[r] * rb[c])) + l2;
+      S[o] = m >= 1e-06f ? l2 : -l2;
+    }
     return 0.f;
   }
   __device__ __forceinline__ void finish(float*, float) const {}
@@ -291,7 +310,13 @@ int st_cosine_distance(const float* x, const float* rx, int nx, const float* y, 
 
 int st_l2_distance(const float* x, const float* xs, int nx, const float* y, const float* ys, int ny, int ld, int d,
                    float* C, int ldc, hipStream_t s) {
-  EpiL2Dist e{xs, ys, C, ldc, nx, ny, 1.0f / (float)d};
+  EpiL2Dist e{xs, ys, C, ldc, nx, ny, (float)d};
+  return launch_pipe<64, 64>(x, ld, nx, 0, y, ld, ny, 0, ld, 1, e, s);
+}
+
+int st_remd_cost(const float* x, const float* rx, const float* sx, int nx, const float* y, const float* ry, const float* sy,
+                 int ny, int ld, int d, int metric, float* C, float* S, int ldc, hipStream_t s) {
+  EpiRemdCost e{rx, ry, sx, sy, C, S, ldc, nx, ny, (float)d, metric};
   return launch_pipe<64, 64>(x, ld, nx, 0, y, ld, ny, 0, ld, 1, e, s);
 }
 

@@ -7,6 +7,8 @@ int st_cosine_distance(const float* x, const float* rx, int nx, const float* y, 
                        int ld, float* C, int ldc, hipStream_t s);
 int st_l2_distance(const float* x, const float* xs, int nx, const float* y, const float* ys, int ny, int ld, int d,
                    float* C, int ldc, hipStream_t s);
+int st_remd_cost(const float* x, const float* rx, const float* sx, int nx, const float* y, const float* ry, const float* sy,
+                 int ny, int ld, int d, int metric, float* C, float* S, int ldc, hipStream_t s);
 int st_gram_tn(const float* A, int krows, int ld, float alpha, float* C, hipStream_t s);
 int st_moment_fwd_gemm(const float* cy, int krows, int ld, const float* Sx, float* T, float inv_n,
                        float* partial, int* n_partial, hipStream_t s);

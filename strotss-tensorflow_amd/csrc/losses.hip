@@ -360,6 +360,78 @@ __global__ __launch_bounds__(256) void remd_cos_bwd_kernel(
   }
 }
 
+// The same for dist_metrics 'l2' (metric 1) and 'both' (metric 2) at any width (losses.py:18-28, 69-80).  C: the cost
+// matrix the minima were taken of (pred-major), S: its l2 part, negative where tf.maximum(m, 1e-6) blocks the gradient.
+//   d l2_ji / d y_j = (y_j - x_i) / (D l2_ji)   [m_ji >= 1e-6],      cosine part as in remd_cos_bwd_kernel with
+//   cos_ji = C_ji - l2_ji.
+__global__ __launch_bounds__(256) void remd_generic_bwd_kernel(
+    const float* __restrict__ C, const float* __restrict__ S, int ldc, const float* __restrict__ style,
+    const float* __restrict__ rs, int ns, const float* __restrict__ pred, const float* __restrict__ rp, int n, int ld,
+    float dwidth, int metric, const float* __restrict__ rmin, const float* __restrict__ rcnt,
+    const float* __restrict__ cmin, const float* __restrict__ ccnt, const int* __restrict__ sel, float gscale,
+    float* __restrict__ gpred) {
+  __shared__ int li[REMD_MAX_LIST];
+  __shared__ float lw[REMD_MAX_LIST];
+  __shared__ float la[REMD_MAX_LIST];
+  __shared__ int cnts[256];
+  __shared__ float red[4];
+  const int j = blockIdx.x, t = threadIdx.x;
+  const int row_branch = sel[0];
+  const int per = (ns + 255) / 256;
+  const int i0 = t * per, i1 = min(ns, i0 + per);
+  const float cm = cmin[j], cc = ccnt[j];
+  int c = 0;
+  for (int i = i0; i < i1; ++i) {
+    const float v = C[(size_t)j * ldc + i];
+    c += row_branch ? (v == rmin[i]) : (v == cm);
+  }
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if ((t & 63) >= o) incl += up;
+  }
+  if ((t & 63) == 63) cnts[t >> 6] = incl;
+  __syncthreads();
+  int off = incl - c, total = 0;
+#pragma unroll
+  for (int wv = 0; wv < 4; ++wv) {
+    off += (wv < (t >> 6)) ? cnts[wv] : 0;
+    total += cnts[wv];
+  }
+  float qpart = 0.f, apart = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const float v = C[(size_t)j * ldc + i];
+    const bool hit = row_branch ? (v == rmin[i]) : (v == cm);
+    if (hit) {
+      const float w = row_branch ? 1.0f / ((float)ns * rcnt[i]) : 1.0f / ((float)n * cc);
+      const float sl = S[(size_t)j * ldc + i], l2 = fabsf(sl);
+      const float a = sl > 0.f ? w / (dwidth * l2) : 0.f;
+      if (off < REMD_MAX_LIST) { li[off] = i; lw[off] = metric == 2 ? w * rs[i] : 0.f; la[off] = a; }
+      if (metric == 2) qpart += w * (1.0f - (v - l2));
+      apart += a;
+      ++off;
+    }
+  }
+  const float q = -block_sum_256(qpart, red);
+  const float asum = block_sum_256(apart, red);     // (also syncs li / lw / la)
+  total = min(total, REMD_MAX_LIST);
+  if (total == 0) return;
+  const float rj = metric == 2 ? rp[j] : 0.f;
+  const float live = (rj < 1.0f / sqrtf(1e-12f)) ? 1.f : 0.f;
+  const float* y = pred + (size_t)j * ld;
+  float* gy = gpred + (size_t)j * ld;
+  for (int k = t; k < ld; k += 256) {
+    float acc = 0.f, accl = 0.f;
+    for (int e = 0; e < total; ++e) {
+      const float xv = style[(size_t)li[e] * ld + k];
+      acc += lw[e] * xv;
+      accl += la[e] * xv;
+    }
+    gy[k] += gscale * (rj * (-acc - y[k] * rj * q * live) + (asum * y[k] - accl));
+  }
+}
+
 // ---------------------------------------------------------------- palette (D = 3, pure VALU)
 // yuv[i] = (Y, U, V, r) with r the inverse norm of the YUV vector  (strotss_utils.py:166-167)
 __global__ __launch_bounds__(256) void palette_prepare_kernel(const float* __restrict__ feat, int n, int ld,
@@ -738,6 +810,21 @@ struct RemdWs {
     return w.ok();
   }
 };
+struct RemdGenWs {          // relaxed_emd with dist_metrics 'l2' / 'both' at any width
+  float *rp, *rs, *sp, *ss, *C, *S, *rmin, *rcnt, *cmin, *ccnt, *pmin, *pcnt;
+  int* sel;
+  int ldt;
+  bool plan(Workspace& w, int ns, int n) {
+    ldt = round_up(ns, 32);
+    const int ldn = round_up(n, 32), ldm = ldn > ldt ? ldn : ldt;
+    rp = w.take<float>(ldn); sp = w.take<float>(ldn); rs = w.take<float>(ldt); ss = w.take<float>(ldt);
+    C = w.take<float>((size_t)n * ldt); S = w.take<float>((size_t)n * ldt);
+    rmin = w.take<float>(ldt); rcnt = w.take<float>(ldt); cmin = w.take<float>(ldn); ccnt = w.take<float>(ldn);
+    pmin = w.take<float>((size_t)COL_CHUNKS * ldm); pcnt = w.take<float>((size_t)COL_CHUNKS * ldm);
+    sel = w.take<int>(4);
+    return w.ok();
+  }
+};
 struct SinkhornWs {
   float *rp, *Mt, *Kt, *W, *U, *DA, *V, *DB, *part, *q, *cost;
   int ldm;
@@ -964,6 +1051,42 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
                      s.cmin, n, 1, loss_out, s.sel);
   hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldt, style, rs, ns, pred, s.rp, n,
                      ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
+  ST_LAUNCH_RET();
+}
+
+size_t strotss_remd_metric_workspace_bytes(int ns, int n) {
+  Workspace w = Workspace::planner();
+  RemdGenWs s;
+  s.plan(w, ns, n);
+  return w.off;
+}
+
+int strotss_remd_metric_fwd_bwd(const float* style, int ns, const float* pred, int n, int d, int ld, int metric,
+                                float gscale, float* gpred, float* loss_out, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  ST_CHECK_ARG(style && pred && gpred && loss_out && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
+  ST_CHECK_ARG(metric == STROTSS_METRIC_L2 || metric == STROTSS_METRIC_BOTH, STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(ns <= REMD_MAX_LIST, STROTSS_ERANGE);
+  Workspace w(workspace, workspace_bytes);
+  RemdGenWs s;
+  ST_CHECK_ARG(s.plan(w, ns, n), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(ns, 4)), dim3(256), 0, st, style, ns, ld, s.rs);
+  hipLaunchKernelGGL(row_sq_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.sp);
+  hipLaunchKernelGGL(row_sq_norm_kernel, dim3(cdiv(ns, 4)), dim3(256), 0, st, style, ns, ld, s.ss);
+  LAUNCH_OK();
+  // pred-major cost matrix Ct[j][i], as in strotss_remd_cos_fwd_bwd: row minima = minima over the style rows per
+  // prediction (cmin, the R_Y side), column minima = minima over the predictions per style row (rmin, the R_X side)
+  const int ldt = s.ldt;
+  CHK(st_remd_cost(pred, s.rp, s.sp, n, style, s.rs, s.ss, ns, ld, d, metric, s.C, s.S, ldt, st));
+  hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.cmin,
+                     s.ccnt, s.pmin, s.pcnt);
+  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin, s.rcnt,
+                     s.cmin, n, 1, loss_out, s.sel);
+  hipLaunchKernelGGL(remd_generic_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, s.S, ldt, style, s.rs, ns, pred, s.rp, n, ld,
+                     (float)d, metric, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
   ST_LAUNCH_RET();
 }
 

@@ -79,6 +79,8 @@ SIGNATURES = {
     "strotss_remd_workspace_bytes": (_Z, [_I, _I, _I]),
     "strotss_remd_cos_fwd_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "strotss_palette_remd_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_remd_metric_workspace_bytes": (_Z, [_I, _I]),
+    "strotss_remd_metric_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "strotss_moment_workspace_bytes": (_Z, [_I, _I]),
     "strotss_moment_stats": (_I, [_P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "strotss_moment_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),

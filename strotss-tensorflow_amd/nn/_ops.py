@@ -428,6 +428,19 @@ def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out, rgb_to_yuv
                                          ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "palette_remd_fwd_bwd")
 
 
+REMD_METRICS = {"l2": 1, "both": 2}      # STROTSS_METRIC_L2 / STROTSS_METRIC_BOTH (include/strotss_hip.h)
+
+
+def remd_metric_fwd_bwd(style, ns, pred, n, d, metric: str, gscale, gpred, loss_out):
+    """relaxed_emd with dist_metrics 'l2' / 'both' at any width (reference losses.py:18-28, 69-80)."""
+    l = _hip.lib()
+    nb = l.strotss_remd_metric_workspace_bytes(ns, n)
+    ws = workspaces.get("remd_metric", nb, pred.device)
+    assert style.shape[1] == pred.shape[1]
+    check(l.strotss_remd_metric_fwd_bwd(ptr(style), ns, ptr(pred), n, d, pred.shape[1], REMD_METRICS[metric], gscale,
+                                        ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "remd_metric_fwd_bwd")
+
+
 def moment_stats(x, n, d):
     l = _hip.lib()
     ld = x.shape[1]

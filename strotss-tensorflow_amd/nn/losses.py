@@ -100,7 +100,11 @@ def self_similarity(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 def relaxed_emd(x: torch.Tensor, y: torch.Tensor, distance: str = 'cosine') -> torch.Tensor:
     """max(mean_i min_j C, mean_j min_i C)  (reference losses.py:69-80); x = target, y = prediction.
-    'cosine' for any width; 'both' (cosine + l2) for width 3 (the palette term)."""
+    Every entry of `dist_metrics` at any width, as the reference (losses.py:27-28, 74): 'cosine' on the bf16x3 cost
+    GEMM, 'l2' and 'both' on the f32-MFMA cost GEMM with the distance in its epilogue; width 3 with 'both' (the palette
+    term of run_strotss.py:36-39) takes the VALU kernel that never stores the cost matrix."""
+    if distance not in dist_metrics:
+        raise KeyError(distance)
     _no_grad_side(x, "relaxed_emd(x, y)")
     bx = _buf(x)
     ns, d = reshape_2d(x).shape
@@ -110,8 +114,8 @@ def relaxed_emd(x: torch.Tensor, y: torch.Tensor, distance: str = 'cosine') -> t
     if distance == 'both' and d == 3:
         return _FusedLoss.apply(y, lambda bp, n, dd, g, loss: _ops.palette_remd_fwd_bwd(bx, ns, bp, n, 1.0, g, loss,
                                                                                        rgb_to_yuv=False))
-    raise NotImplementedError(f"relaxed_emd(distance={distance!r}, width={d}): the HIP path covers 'cosine' "
-                              f"and 'both' at width 3 (what run_strotss.py uses)")
+    return _FusedLoss.apply(y, lambda bp, n, dd, g, loss: _ops.remd_metric_fwd_bwd(bx, ns, bp, n, dd, distance, 1.0, g,
+                                                                                  loss))
 
 
 def sinkhorn_knopp(x: torch.Tensor, y: torch.Tensor, distance: str = 'cosine', l: int = 10,

@@ -3,8 +3,8 @@
 The reference seeds python/numpy/TF with 0 and draws the sample coordinates from
 `tf.random.Generator.from_seed(0)` + `tf.random.shuffle`.  TF's Philox streams cannot be
 reproduced without TF, so "identical seeds" means here: identical *index sequences*, produced by
-`index_rng` (a NumPy Generator, seed 0) and injectable everywhere (`Sampling(indices=...)`,
-`engine.ScaleRun(index_stream=...)`).  The reference also pins TF to one inter-op and one intra-op
+`index_rng` (a NumPy Generator, seed 0) and injectable everywhere (`Sampling(..., rng=...)`,
+`Sampling.__call__(..., indices=...)`, the index sets passed to `engine.StepEngine.step`).  The reference also pins TF to one inter-op and one intra-op
 thread; there is no host compute left to pin in this build."""
 import os
 import random

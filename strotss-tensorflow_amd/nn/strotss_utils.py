@@ -193,24 +193,27 @@ def postprocess(final: torch.Tensor) -> torch.Tensor:
     return _ops.postprocess(final.detach().float().contiguous())[0]
 
 
+def _colour_keys(path: str, max_size: Optional[int], pixel_threth: int) -> np.ndarray:
+    """(H, W) int64 key per pixel of a colour-coded region image: its channels floored to multiples of `pixel_threth`
+    (uint8 as decoded, or float32 when `max_size` made load_image resize it) and packed so that ascending keys are
+    ascending (r, g, b) triples."""
+    img = utils.load_image(path, max_size, dtype=torch.uint8, batch_expand=False).cpu().numpy()
+    q = (np.floor_divide(img, pixel_threth) * pixel_threth).astype(np.int64)
+    return (q[..., 0] << 32) | (q[..., 1] << 16) | q[..., 2]
+
+
 def load_mask(content_path: str, style_path: str, max_size: Optional[int],
               pixel_threth: int = 255, sample_threth: int = 10000):
-    """reference strotss_utils.py:178-201: paired region masks from two colour-coded images."""
-    c_mask = utils.load_image(content_path, max_size, dtype=torch.uint8, batch_expand=False).cpu().numpy()
-    c_mask = c_mask // pixel_threth * pixel_threth
-    s_mask = utils.load_image(style_path, max_size, dtype=torch.uint8, batch_expand=False).cpu().numpy()
-    s_mask = s_mask // pixel_threth * pixel_threth
-
-    uniques, counts = np.unique(c_mask.reshape(-1, 3), axis=0, return_counts=True)
-    uniques = uniques[counts >= sample_threth]        # to avoid too small mask
-
-    c_ret, s_ret = [], []
-    for unique in uniques:
-        c_condition = (c_mask[..., 0] == unique[0]) & (c_mask[..., 1] == unique[1]) & (c_mask[..., 2] == unique[2])
-        s_condition = (s_mask[..., 0] == unique[0]) & (s_mask[..., 1] == unique[1]) & (s_mask[..., 2] == unique[2])
-        if np.any(c_condition) and np.any(s_condition):
-            c_ret.append(torch.from_numpy(c_condition.astype(np.float32))[..., None])
-            s_ret.append(torch.from_numpy(s_condition.astype(np.float32))[..., None])
-    if not c_ret:
+    """reference strotss_utils.py:178-201: paired (H, W, 1) float 0/1 region masks from two colour-coded images -- one
+    pair per colour that covers at least `sample_threth` content pixels and occurs in the style image too, in ascending
+    (r, g, b) order; bare Exception('No mask found') when there is none."""
+    c_keys = _colour_keys(content_path, max_size, pixel_threth)
+    s_keys = _colour_keys(style_path, max_size, pixel_threth)
+    colours, counts = np.unique(c_keys, return_counts=True)
+    chosen = colours[(counts >= sample_threth) & np.isin(colours, s_keys)]
+    if chosen.size == 0:
         raise Exception('No mask found')
-    return c_ret, s_ret
+
+    def region(keys: np.ndarray, colour) -> torch.Tensor:
+        return torch.from_numpy((keys == colour).astype(np.float32))[..., None]
+    return [region(c_keys, c) for c in chosen], [region(s_keys, c) for c in chosen]

@@ -82,7 +82,7 @@ def test_trace_against_fixture():
         assert abs(got["loss"] - z["trace"][it, 0]) < 2e-2 * it * abs(z["trace"][it, 0]), (it, got["loss"], z["trace"][it, 0])
     out = eng.stylized()
     assert np.abs(out.cpu().numpy() - z["final"]).mean() < 0.03
-    # postprocess kernel on the FIXTURE's final float image == the fixture's uint8 (truncation boundary: +-1)
-    u8 = SU.postprocess(dev(z["final"])).cpu().numpy().astype(int)
-    d = np.abs(u8 - z["final_u8"].astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 0.01
+    # postprocess kernel on the FIXTURE's final float image == the fixture's uint8, byte for byte (the fixture's bytes are
+    # the oracle's float32 arithmetic on the float32 cast of `final`, which is what dev() uploads)
+    u8 = SU.postprocess(dev(z["final"])).cpu().numpy()
+    assert u8.dtype == np.uint8 and np.array_equal(u8, z["final_u8"]), int((u8 != z["final_u8"]).sum())

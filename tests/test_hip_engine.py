@@ -296,6 +296,42 @@ def test_losses_api_autograd():
         L.sinkhorn_knopp(xd, yd, distance='l2')
 
 
+@pytest.mark.parametrize("distance", ["l2", "both", "cosine"])
+@pytest.mark.parametrize("shape", [(96, 80, 131), (64, 100, 3), (200, 150, 35), (33, 257, 2179), (50, 40, 1)])
+def test_relaxed_emd_every_metric_any_width(distance, shape):
+    """relaxed_emd(x, y, distance) for every entry of dist_metrics at any width (reference losses.py:27-28, 69-80):
+    value and d/dy against the float64 autograd restatement; a duplicated style row and a duplicated prediction row make
+    ties that tf.reduce_min splits; a prediction row equal to a style row exercises the 1e-6 clamp of l2_distance."""
+    from nn import losses as L
+    n, ns, d = shape
+    rng = np.random.default_rng(n * 7 + ns + d)
+    mk = lambda r, c: np.abs(rng.standard_normal((r, c))) + 0.01
+    x, y = mk(ns, d), mk(n, d)
+    x[3] = x[1]                       # tie along the style axis
+    y[5] = y[2]                       # tie along the prediction axis
+    y[7] = x[4]                       # m = |x|^2 + |y|^2 - 2 x.y ~ 0: clamped, no l2 gradient
+    xt = torch.from_numpy(x)
+    yt = torch.from_numpy(y).clone().requires_grad_(True)
+    ref = O.relaxed_emd(xt, yt, distance)
+    gref, = torch.autograd.grad(ref, yt)
+    yd = torch.from_numpy(y).float().to(DEV).requires_grad_(True)
+    got = L.relaxed_emd(torch.from_numpy(x).float().to(DEV), yd, distance)
+    got.backward()
+    assert abs(float(got) - float(ref)) < 5e-5 * abs(float(ref)) + 1e-6, (float(got), float(ref))
+    g = yd.grad.cpu().double()
+    if d == 1 and distance == "cosine":          # every cosine distance is 0 at width 1: no gradient to compare
+        assert float(g.norm()) < 1e-4
+        return
+    # the clamped pair: float32 rounding decides on which side of 1e-6 `m` falls, in the oracle (float64: exactly 0) it
+    # is clamped -> compare all other rows, and require row 7's gradient to be finite
+    keep = torch.ones(n, dtype=torch.bool); keep[7] = False
+    rel = float((g[keep] - gref[keep]).norm() / gref[keep].norm())
+    assert rel < 3e-3, rel
+    assert torch.isfinite(g).all()
+    with pytest.raises(KeyError):
+        L.relaxed_emd(torch.from_numpy(x).float().to(DEV), yd, 'manhattan')
+
+
 @pytest.mark.parametrize("cfg", [(96, 80, 131, 10, 30), (64, 100, 67, 5, 12), (200, 200, 35, 10, 30)])
 def test_sinkhorn_knopp_matches_float64_autograd(cfg):
     """Build-defined Sinkhorn cost (losses.py:83-105 is dead code in the reference): value and the gradient through

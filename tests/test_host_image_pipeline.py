@@ -55,3 +55,49 @@ def test_writer_is_always_a_quality_100_420_jpeg(tmp_path):
         utils.write_image(torch.zeros(2, 4, 4, 3), str(tmp_path / "bad.jpg"))
     with pytest.raises(FileNotFoundError):
         utils.load_image(str(tmp_path / "missing.jpg"))
+
+
+def _literal_load_mask(c_mask, s_mask, pixel_threth, sample_threth):
+    """The reference's algorithm (nn/strotss_utils.py:178-201) written out naively: per-colour loops over np.unique rows."""
+    c = c_mask // pixel_threth * pixel_threth
+    s = s_mask // pixel_threth * pixel_threth
+    rows, counts = np.unique(c.reshape(-1, 3), axis=0, return_counts=True)
+    pairs = []
+    for row, cnt in zip(rows, counts):
+        if cnt < sample_threth:
+            continue
+        cm = np.all(c == row, axis=-1)
+        sm = np.all(s == row, axis=-1)
+        if cm.any() and sm.any():
+            pairs.append((cm.astype(np.float32)[..., None], sm.astype(np.float32)[..., None]))
+    return pairs
+
+
+@pytest.mark.parametrize("pixel_threth", [255, 128])
+def test_load_mask_pairs_regions_like_the_reference(tmp_path, pixel_threth):
+    """load_mask on lossless colour-coded images: region order (ascending r, g, b), the size threshold, colours missing
+    from the style image dropped, float (H, W, 1) 0/1 masks, bare Exception when nothing pairs (a19)."""
+    from PIL import Image
+    from nn import strotss_utils as SU
+    rng = np.random.default_rng(0)
+    palette = np.array([[0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [130, 140, 250]], np.uint8)
+    c = palette[rng.integers(0, 4, size=(12, 16))].repeat(16, 0).repeat(16, 1)        # 192 x 256, blocks of 16 x 16
+    c[:8, :8] = palette[4]                                                            # 64 px: under every threshold used
+    c[100:180, 30:200] = palette[5]                                                   # only quantises away at 255
+    s = palette[rng.integers(0, 3, size=(10, 10))].repeat(20, 0).repeat(20, 1)        # blue never occurs in the style
+    s[50:120, 50:120] = palette[5]
+    Image.fromarray(c, "RGB").save(tmp_path / "c.png")
+    Image.fromarray(s, "RGB").save(tmp_path / "s.png")
+    for thr in (1, 3000, 10000):
+        want = _literal_load_mask(c, s, pixel_threth, thr)
+        if not want:
+            with pytest.raises(Exception, match="No mask found"):
+                SU.load_mask(str(tmp_path / "c.png"), str(tmp_path / "s.png"), None, pixel_threth, thr)
+            continue
+        cm, sm = SU.load_mask(str(tmp_path / "c.png"), str(tmp_path / "s.png"), None, pixel_threth, thr)
+        assert len(cm) == len(sm) == len(want)
+        for a, b, (wa, wb) in zip(cm, sm, want):
+            assert a.dtype == torch.float32 and tuple(a.shape) == (192, 256, 1) and tuple(b.shape) == (200, 200, 1)
+            assert np.array_equal(a.numpy(), wa) and np.array_equal(b.numpy(), wb)
+    with pytest.raises(Exception, match="No mask found"):
+        SU.load_mask(str(tmp_path / "c.png"), str(tmp_path / "s.png"), None, pixel_threth, 10 ** 9)

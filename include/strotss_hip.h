@@ -104,10 +104,8 @@ int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const fl
  * (strotss_conv3x3_winograd_x3_bytes bytes).  With it, the 36 GEMMs of the three-kernel form run on the bf16 MFMA by
  * EXACT 3-way operand splitting (every f32 value = h + m + l in bf16, six exact partial products, f32 accumulation:
  * f32-class results at 6/16 of the f32-MFMA cost, csrc/mfma_x3.h).  Default on (STROTSS_X3_CONV=0 switches it off).
- * u_packed_x3 (tile_m = 4 only, may be NULL): the same weights as split planes in the fragment order of the FUSED
- * bf16x3 kernel (csrc/winograd_fused_x3.hip), written by strotss_conv3x3_winograd_pack_x3 (as many bytes as u_x3).
- * With it, the layers that run as one persistent kernel take their 36 products on the bf16 MFMA as well (same exact
- * split; STROTSS_WINO_FUSED_X3=0 selects the f32-MFMA kernel, which needs u_packed). */
+ * (Round 2's two bf16x3 forms of the FUSED kernel, both measured slower than its f32-MFMA form, left the library and
+ * this ABI in round 3: tools/experiments/winograd_fused_x3.hip.) */
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m);
 /* The Winograd weight transform itself: g_nk33 (n, k, 3, 3) = kernel as [out-row][in-col][r][q] -> u_pnk (P, n, k) with
  * u_pnk[a * (tile_m + 2) + b] = (G g G^T)[a][b], P = (tile_m + 2)^2, computed in float64 and rounded once. */
@@ -119,21 +117,16 @@ int strotss_conv3x3_winograd_x3pack(const float* u_prk, int rows, int k, void* u
 /* u_prk: (36, rows, k) -> u_packed[p][rows/32][k/8][2][32][4]: element (p, r, c) at
  * ((((p * (rows/32) + r/32) * (k/8) + c/8) * 2 + (c%8)/4) * 32 + r%32) * 4 + c%4.  rows % 32 == 0, k % 8 == 0. */
 int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_packed, void* stream);
-/* u_prk: (36, rows, k) -> u_packed_x3: per (position p, group r/32, chunk c/8) the bf16 planes h, m, l of the 32 x 8
- * block, [plane][32 rows][8 channels]: element (p, r, c, plane) at
- * ((((p * (rows/32) + r/32) * (k/8) + c/8) * 3 + plane) * 32 + r%32) * 8 + c%8  (bf16 units);
- * strotss_conv3x3_winograd_x3_bytes(rows, k) bytes.  rows % 32 == 0, k % 8 == 0. */
-int strotss_conv3x3_winograd_pack_x3(const float* u_prk, int rows, int k, void* u_packed_x3, void* stream);
 /* pool_out (may be NULL): also writes strotss_maxpool2_fwd(out) = the (h/2, w/2, cout) input of the next block --
  * from the registers of the fused kernel's epilogue where that kernel runs, by a pooling launch otherwise;
  * pool_code (may be NULL, needs pool_out): the argmax codes of that pooling, see strotss_maxpool2_fwd. */
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok,
-                                 const float* u_packed, const void* u_packed_x3, const void* u_x3, const float* bias,
+                                 const float* u_packed, const void* u_x3, const float* bias,
                                  int cout, int tile_m, float* out,
                                  float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
                                  void* stream);
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
-                                   const float* u_packed, const void* u_packed_x3, const void* u_x3, int cin, int tile_m,
+                                   const float* u_packed, const void* u_x3, int cin, int tile_m,
                                    const float* act_in, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream);
 /* 2x2/2 VALID max-pool: out(h/2, w/2, c).  code (may be NULL): (h/2, w/2, c) bytes, the index 0..3 of the FIRST

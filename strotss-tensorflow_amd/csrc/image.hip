@@ -388,7 +388,7 @@ int maps_ok(const strotss_maps_t* m) {
 
 extern "C" {
 
-int strotss_abi_version(void) { return 3; }
+int strotss_abi_version(void) { return 4; }
 const char* strotss_build_info(void) { return "libstrotss_hip gfx950 fp32-mfma " __DATE__ " " __TIME__; }
 
 int strotss_resize_bilinear(const float* in, int ih, int iw, int c, float* out, int oh, int ow, float alpha,
@@ -428,7 +428,9 @@ int strotss_hypercol_gather(const strotss_maps_t* maps, const float* idx, int n,
   int d = 0;
   for (int k = 0; k < maps->n_maps; ++k) d += maps->c[k];
   ST_CHECK_ARG(ld >= d, STROTSS_EINVAL);
-  hipLaunchKernelGGL(hypercol_gather_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, *maps, idx, bilinear,
+  strotss_maps_t m = *maps;
+  m.window_drop = 0;          // the gather ALWAYS clamps into the window; dropping is the scatter's (adjoint's) business
+  hipLaunchKernelGGL(hypercol_gather_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, m, idx, bilinear,
                      out, ld, d);
   ST_LAUNCH_RET();
 }

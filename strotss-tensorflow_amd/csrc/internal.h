@@ -25,11 +25,6 @@ bool st_winograd43_fused_enabled(int h, int w, int cout);
 int st_winograd43_pack(const float* u_prk, int rows, int k, float* u_packed, hipStream_t st);
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                         const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code, hipStream_t st);
-// winograd_fused_x3.hip: the same kernel with the 36 products on the bf16 MFMA (exact 3-way operand split)
-bool st_winograd43_fused_x3_enabled();
-int st_winograd43_pack_x3(const float* u_prk, int rows, int k, void* u_packed_x3, hipStream_t st);
-int st_winograd43_fused_x3(const float* in, int h, int w, int cin, const void* U, const float* bias, int cout,
-                           const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code, hipStream_t st);
 int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, hipStream_t st);
 
 // f32 GEMM cores on the bf16 MFMA (mfma_x3.h): operands as "x3 panels" (3 * rows * K bf16 per batch entry)

@@ -312,17 +312,14 @@ static bool winograd43_prefers_x3(int h, int w, int cout) {
 }
 
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* Upacked,
-                          const void* Upacked_x3, const void* Ux3, const float* bias, int cout, const float* mask, int relu, float* out,
+                          const void* Ux3, const float* bias, int cout, const float* mask, int relu, float* out,
                           float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
                           hipStream_t st) {
   // 256 output channels and enough tiles for the bf16x3 GEMMs: the three-kernel form wins (1024-px step 5.102 -> 5.039 ms,
   // three alternating runs each); STROTSS_X3_MIN_COUT (default 256) moves the border
   const bool prefer_x3 = Ux3 && cin % 32 == 0 && winograd43_prefers_x3(h, w, cout);
-  if (!prefer_x3 && (Upacked || Upacked_x3) && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout)) {   // everything on chip
-    if (Upacked_x3 && st_winograd43_fused_x3_enabled())
-      return st_winograd43_fused_x3(in, h, w, cin, Upacked_x3, bias, cout, mask, relu, out, pool_out, pool_code, st);
-    if (Upacked) return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, st);
-  }
+  if (!prefer_x3 && Upacked && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout))      // everything on chip
+    return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, st);
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const size_t T = (size_t)TH * TW;
   const bool x3 = Ux3 && cin % 32 == 0 && x3_enabled(T, cout);
@@ -442,19 +439,18 @@ size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout,
 }
 
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok, const float* u_packed,
-                                 const void* u_packed_x3, const void* u_x3, const float* bias, int cout, int tile_m, float* out, float* pool_out,
+                                 const void* u_x3, const float* bias, int cout, int tile_m, float* out, float* pool_out,
                                  unsigned char* pool_code, void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(in && u_pok && bias && out && workspace && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   ST_CHECK_ARG(!pool_out || (h >= 2 && w >= 2), STROTSS_EINVAL);
   ST_CHECK_ARG(!pool_code || pool_out, STROTSS_EINVAL);
-  bool fused = tile_m == 4 && (u_packed || (u_packed_x3 && st_winograd43_fused_x3_enabled())) && cin % 32 == 0 &&
-               st_winograd43_fused_enabled(h, w, cout);
+  bool fused = tile_m == 4 && u_packed && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout);
   if (fused && u_x3 && winograd43_prefers_x3(h, w, cout)) fused = false;
   int rc;
   if (tile_m == 4)
-    rc = winograd43_run(in, h, w, cin, u_pok, u_packed, u_packed_x3, u_x3, bias, cout, nullptr, 1, out, pool_out, pool_code, workspace,
+    rc = winograd43_run(in, h, w, cin, u_pok, u_packed, u_x3, bias, cout, nullptr, 1, out, pool_out, pool_code, workspace,
                         workspace_bytes, (hipStream_t)stream);
   else
     rc = winograd_run(in, h, w, cin, u_pok, bias, cout, nullptr, 1, out, workspace, workspace_bytes,
@@ -464,14 +460,14 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
 }
 
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
-                                   const float* u_packed, const void* u_packed_x3, const void* u_x3, int cin, int tile_m,
+                                   const float* u_packed, const void* u_x3, int cin, int tile_m,
                                    const float* act_in, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(gout && u_pik && gin && workspace && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   if (tile_m == 4)
-    return winograd43_run(gout, h, w, cout, u_pik, u_packed, u_packed_x3, u_x3, nullptr, cin, act_in, 0, gin, nullptr, nullptr, workspace,
+    return winograd43_run(gout, h, w, cout, u_pik, u_packed, u_x3, nullptr, cin, act_in, 0, gin, nullptr, nullptr, workspace,
                           workspace_bytes, (hipStream_t)stream);
   return winograd_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
                       (hipStream_t)stream);
@@ -483,12 +479,6 @@ int strotss_conv3x3_winograd_x3pack(const float* u_prk, int rows, int k, void* u
   ST_CHECK_ARG(u_prk && u_x3 && rows > 0 && k > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(k % 32 == 0, STROTSS_EALIGN);
   return st_x3_split_rows(u_prk, rows, k, k, (long long)rows * k, u_x3, 36, (hipStream_t)stream);
-}
-
-int strotss_conv3x3_winograd_pack_x3(const float* u_prk, int rows, int k, void* u_packed_x3, void* stream) {
-  ST_CHECK_ARG(u_prk && u_packed_x3 && rows > 0 && k > 0, STROTSS_EINVAL);
-  ST_CHECK_ARG(rows % 32 == 0 && k % 8 == 0, STROTSS_EALIGN);
-  return st_winograd43_pack_x3(u_prk, rows, k, u_packed_x3, (hipStream_t)stream);
 }
 
 int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_packed, void* stream) {

@@ -77,49 +77,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct ItemRef { int goff[F_NLOAD]; unsigned okm; int g; };
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-// exact split of two f32 values into three dwords of 2 x bf16 (h, m, l planes)
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  const bf16x2_t hb = {(__bf16)x0, (__bf16)x1};
-  const float r0 = x0 - (float)hb[0], r1 = x1 - (float)hb[1];
-  const bf16x2_t mb = {(__bf16)r0, (__bf16)r1};
-  const float s0 = r0 - (float)mb[0], s1 = r1 - (float)mb[1];
-  const bf16x2_t lb = {(__bf16)s0, (__bf16)s1};
-  h = __builtin_bit_cast(unsigned, hb); m = __builtin_bit_cast(unsigned, mb); l = __builtin_bit_cast(unsigned, lb);
-}
-// acc += (4 channels of a) x (4 channels of b) summed over the lane halves: six exact partial products, smallest first
-__device__ __forceinline__ void x3_unit(const f32x4 a, const f32x4 b, f32x16& acc) {
-  unsigned ah0, am0, al0, ah1, am1, al1, bh0, bm0, bl0, bh1, bm1, bl1;
-  split2(a[0], a[1], ah0, am0, al0); split2(a[2], a[3], ah1, am1, al1);
-  split2(b[0], b[1], bh0, bm0, bl0); split2(b[2], b[3], bh1, bm1, bl1);
-  const u32x4_t a_hl = {ah0, ah1, al0, al1}, a_mm = {am0, am1, am0, am1}, a_hh = {ah0, ah1, ah0, ah1};
-  const u32x4_t b_lh = {bl0, bl1, bh0, bh1}, b_hm = {bh0, bh1, bm0, bm1};
-#ifndef FUSED_NO_MFMA
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_hl), __builtin_bit_cast(bf16x8_t, b_lh), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_mm), __builtin_bit_cast(bf16x8_t, b_hm), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_hh), __builtin_bit_cast(bf16x8_t, b_hm), acc, 0, 0, 0);
-#else
-  acc[0] += __builtin_bit_cast(float, a_hl[0] ^ b_lh[1] ^ a_mm[2] ^ b_hm[3] ^ a_hh[1]);
-#endif
-}
-
 // in: (H, W, K) NHWC, K % 32 == 0; U: fragment-major (36, Cout, K) weights; out / mask: (H, W, Cout), Cout % 32 == 0.
 // !MASK: out = relu ? max(Y + bias, 0) : Y + bias;  MASK: out = mask > 0 ? Y : 0.
 // Work item = (region r of 16x32 output pixels, row-major) x (group g of 32 couts): item = r * NG + g.  The grid is
 // persistent; workgroup b walks the items of its XCD's contiguous range, so the NG groups of a region (same input
 // patch) run on neighbouring CUs of one XCD at the same time and share its L2.
-// X3: the 36 products on the bf16 MFMA by EXACT 3-way operand splitting in registers (mfma_x3.h: every f32 value is
-// h + m + l in bf16, six exact partial products, f32 accumulation -- f32-class results).  Same LDS images, same weight
-// format, same pipeline as the f32-MFMA form; only the product stage differs.  Lane (row l31, half hh) holds 4 of the
-// chunk's 8 channels of its V row / U row (f32x4), splits them itself (no value is split twice) and feeds
-// v_mfma_f32_32x32x16_bf16 with K = 16 = two planes of ITS 4 channels side by side (k = 8 hh + i: i < 4 first plane,
-// i >= 4 second plane; both operands alike):
-//     [a_h | a_l] x [b_l | b_h] -> hl + lh,   [a_m | a_m] x [b_h | b_m] -> mh + mm,   [a_h | a_h] x [b_h | b_m] -> hh + hm.
-// Why: the f32 MFMA blocks the SIMD's vector issue for its whole 64 cycles (4 per unit and chunk = 256 cycles), the
-// bf16 MFMA for 8 of its 32 (3 per unit = 96 cycles, 24 of them blocking): the transform and the splits run beside it.
-template <bool MASK, bool X3>
+// The 36 products on the bf16 MFMA with the operands split exactly in registers (round 2: 353 us against 338 us for
+// block1_conv2 forward, the splits' vector instructions take the place of the shorter MFMAs) and a pre-split-planes
+// variant live in tools/experiments/ with their ablation tool; DESIGN.md 4 has the measurements.
+template <bool MASK>
 __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __restrict__ in, int H, int W, int K,
                                                                 const float* __restrict__ U, int Cout,
                                                                 const float* __restrict__ bias,
@@ -279,13 +245,9 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
       if (t < 256) ABL_T(transform(Rb + (1 - PAR) * F_RAW, Vb + (1 - PAR) * F_V));                            \
       PROF(2);                                                                                                \
       _Pragma("unroll") for (int j = 0; j < 3; ++j) a[j] = *reinterpret_cast<const f32x4*>(Vc + j * a_step);  \
-      if constexpr (X3) {                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) x3_unit(a[j], BCUR[j], acc[j]);                         \
-      } else {                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                         \
-          _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                       \
-            MFMA_STEP(a[j][s], BCUR[j][s], acc[j]);                                                           \
-      }                                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                           \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                         \
+          MFMA_STEP(a[j][s], BCUR[j][s], acc[j]);                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
       PROF(3);                                                                                                \
@@ -507,21 +469,9 @@ int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, 
   }
   int grid = cus;                                  // persistent: one 147 KB-LDS workgroup per CU, a multiple of 8
   while (grid > 8 && grid / 2 >= nitems) grid /= 2;
-  // STROTSS_WINO_FUSED_PROD: "f32" (default) = f32 MFMA; "x3" = the products on the bf16 MFMA, operands split in
-  // registers.  Measured on the 1024-px step (three alternating runs each): 5.273 +- 0.021 ms (f32) against
-  // 5.327 +- 0.021 ms (x3); block1_conv2 forward 338 -> 353 us.  The MFMA time does shrink (2304 -> 864 cycles per
-  // phase and SIMD) but the 44 vector instructions per unit of the two splits take its place, and the phase is
-  // bounded by what neither form changes: the cache-line requests of the patch and U loads and the LDS traffic.
-  static int x3 = -1;
-  if (x3 < 0) {
-    const char* e = getenv("STROTSS_WINO_FUSED_PROD");
-    x3 = (e && e[0] == 'x');
-    const char* g = getenv("STROTSS_X3"); if (g && atoi(g) == 0) x3 = 0;
-  }
-#define LAUNCH_FUSED(M, X) hipLaunchKernelGGL((winograd43_fused_kernel<M, X>), dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, \
-                                              cin, U, cout, bias, mask, relu, out, pool_out, pool_code, RW, NG, nitems)
-  if (mask) { if (x3) LAUNCH_FUSED(true, true); else LAUNCH_FUSED(true, false); }
-  else { if (x3) LAUNCH_FUSED(false, true); else LAUNCH_FUSED(false, false); }
+#define LAUNCH_FUSED(M) hipLaunchKernelGGL((winograd43_fused_kernel<M>), dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, \
+                                           cin, U, cout, bias, mask, relu, out, pool_out, pool_code, RW, NG, nitems)
+  if (mask) LAUNCH_FUSED(true); else LAUNCH_FUSED(false);
 #undef LAUNCH_FUSED
   ST_LAUNCH_RET();
 }

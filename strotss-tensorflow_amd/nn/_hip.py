@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STROTSS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libstrotss_hip.so")
 
 MAX_MAPS, MAX_DIVS, MAX_TENSORS = 12, 8, 8
+ABI_VERSION = 4          # must equal strotss_abi_version() of the loaded library (argument lists change with it)
 
 
 class StrotssHipError(RuntimeError):
@@ -57,9 +58,8 @@ SIGNATURES = {
     "strotss_conv3x3_winograd_pack": (_I, [_P, _I, _I, _P, _P]),
     "strotss_conv3x3_winograd_x3_bytes": (_Z, [_I, _I]),
     "strotss_conv3x3_winograd_x3pack": (_I, [_P, _I, _I, _P, _P]),
-    "strotss_conv3x3_winograd_pack_x3": (_I, [_P, _I, _I, _P, _P]),
-    "strotss_conv3x3_winograd_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
-    "strotss_conv3x3_winograd_dgrad": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _P]),
+    "strotss_conv3x3_winograd_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    "strotss_conv3x3_winograd_dgrad": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _P]),
     "strotss_maxpool2_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "strotss_maxpool2_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "strotss_hypercol_gather": (_I, [C.POINTER(MapsT), _P, _I, _I, _P, _I, _P]),
@@ -105,6 +105,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)            # AttributeError -> missing export
         fn.restype = res
         fn.argtypes = args
+    got = lib.strotss_abi_version()
+    if got != ABI_VERSION:
+        raise StrotssHipError(f"{path} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild it "
+                              f"(`make -C strotss-tensorflow_amd/csrc`); a stale library would be called with shifted arguments")
     _lib = lib
     return lib
 

@@ -20,6 +20,14 @@ def pad32(v: int) -> int:
     return (v + 31) // 32 * 32
 
 
+def canonical_device(device) -> torch.device:
+    """torch.device with an explicit index ("cuda" -> "cuda:<current>"), comparable with Tensor.device."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 def hwc(t: torch.Tensor) -> Tuple[int, int, int]:
     return int(t.shape[-3]), int(t.shape[-2]), int(t.shape[-1])
 
@@ -136,31 +144,6 @@ def winograd_packed(u: torch.Tensor):
     return up
 
 
-_packed_x3 = {}    # id(u) -> (weakref(u), planes): split planes of frozen F(4x4,3x3) weights for the fused bf16x3 kernel
-
-
-def winograd_packed_x3(u: torch.Tensor):
-    """The h / m / l bf16 planes of a (36, rows, k) Winograd weight tensor in the fragment order of the fused bf16x3
-    kernel (csrc/winograd_fused_x3.hip; made once per tensor object), or None where that kernel does not apply."""
-    import os, weakref
-    if int(u.shape[0]) != 36 or int(u.shape[1]) % 32 or int(u.shape[2]) % 32 or int(u.shape[1]) > 256 \
-            or os.environ.get("STROTSS_X3", "1") == "0" or os.environ.get("STROTSS_WINO_FUSED_X3", "0") == "0" \
-            or os.environ.get("STROTSS_WINO_FUSED", "1") == "0":
-        return None
-    hit = _packed_x3.get(id(u))
-    if hit is not None and hit[0]() is u:
-        return hit[1]
-    require(u, "winograd weights")
-    rows, k = int(u.shape[1]), int(u.shape[2])
-    nb = _hip.lib().strotss_conv3x3_winograd_x3_bytes(rows, k)
-    up = torch.empty(nb // 2, dtype=torch.bfloat16, device=u.device)
-    check(_hip.lib().strotss_conv3x3_winograd_pack_x3(ptr(u), rows, k, ptr(up), stream_ptr()), "conv3x3_winograd_pack_x3")
-    for key in [key for key, v in _packed_x3.items() if v[0]() is None]:
-        del _packed_x3[key]
-    _packed_x3[id(u)] = (weakref.ref(u), up)
-    return up
-
-
 _x3 = {}           # id(u) -> (weakref(u), panels): bf16x3 "x3 panels" of frozen F(4x4,3x3) weights
 
 
@@ -208,9 +191,10 @@ def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None
     if out is None:
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
     m = _tile_m(u_pok)
+    assert u_pok.device == x.device, (u_pok.device, x.device)
     ws, nb = _wino_ws(h, w, cin, cout, m, x.device)
     check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(winograd_packed(u_pok)),
-                                                  ptr(winograd_packed_x3(u_pok)), ptr(winograd_x3(u_pok, h, w)), ptr(bias),
+                                                  ptr(winograd_x3(u_pok, h, w)), ptr(bias),
                                                   cout, m, ptr(out), ptr(pool_out), ptr(pool_code), ptr(ws), nb, stream_ptr()),
           "conv3x3_winograd_fwd")
     return out
@@ -221,24 +205,28 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
     if out is None:
         out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
     m = _tile_m(u_pik)
+    assert u_pik.device == gout.device, (u_pik.device, gout.device)
     ws, nb = _wino_ws(h, w, cout, cin, m, gout.device)
     check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), ptr(winograd_packed(u_pik)),
-                                                    ptr(winograd_packed_x3(u_pik)), ptr(winograd_x3(u_pik, h, w)), cin,
+                                                    ptr(winograd_x3(u_pik, h, w)), cin,
                                                     m, ptr(act_in), ptr(out), ptr(ws), nb, stream_ptr()),
           "conv3x3_winograd_dgrad")
     return out
 
 
-def winograd_weights(g: torch.Tensor, tile_m: int = 2) -> torch.Tensor:
+def winograd_weights(g: torch.Tensor, tile_m: int = 2, device=None) -> torch.Tensor:
     """g: (N, K, 3, 3) kernel as [out-channel][in-channel][r][q] -> U (P, N, K) float32 with
-    U[a*(m+2)+b] = (G g G^T)[a, b], computed in float64 on the device (P = 16 for tile_m = 2, 36 for tile_m = 4)."""
-    if not g.is_cuda:
-        g = g.to(torch.device("cuda", torch.cuda.current_device())) if torch.cuda.is_available() else g
+    U[a*(m+2)+b] = (G g G^T)[a, b], computed in float64 on the device (P = 16 for tile_m = 2, 36 for tile_m = 4).
+    `device`: where a host-held `g` goes (the model's device; default: the current one)."""
+    if not g.is_cuda and torch.cuda.is_available():
+        g = g.to(canonical_device(device if device is not None else "cuda"))
     g = g.float().contiguous()
     require(g, "conv kernel")
     n, k = int(g.shape[0]), int(g.shape[1])
     u = torch.empty(((tile_m + 2) ** 2, n, k), dtype=torch.float32, device=g.device)
-    check(_hip.lib().strotss_conv3x3_winograd_weights(ptr(g), n, k, tile_m, ptr(u), stream_ptr()), "conv3x3_winograd_weights")
+    with torch.cuda.device(g.device):          # stream_ptr() is the CURRENT device's stream: make that device g's
+        check(_hip.lib().strotss_conv3x3_winograd_weights(ptr(g), n, k, tile_m, ptr(u), stream_ptr()),
+              "conv3x3_winograd_weights")
     return u
 
 

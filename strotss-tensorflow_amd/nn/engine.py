@@ -138,7 +138,10 @@ class StepEngine:
         # deterministic mode (STROTSS_DETERMINISTIC=1): the tap adjoint as a sorted scatter, one plan per region and step
         # (no float atomics -> bitwise reproducible steps; the reference asks TF for the same: nn/rand.py:4-8)
         import os
-        self.deterministic = (os.environ.get("STROTSS_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
+        # default: off with a GPU to itself; ON when several ranks share one card (parallel.ranks_share_a_gpu)
+        env = os.environ.get("STROTSS_DETERMINISTIC")
+        self.deterministic = bool(deterministic) if deterministic is not None else \
+            (env == "1" if env is not None else parallel.ranks_share_a_gpu())
         self._plans = None
         if self.deterministic:
             nb = _hip.lib().strotss_hypercol_scatter_plan_bytes(len(self.pred_maps))

@@ -121,13 +121,14 @@ def winograd_tile(h: int, w: int, cin: int = 128, cout: int = 0) -> int:
 class _LazyWinograd:
     """u[m] = Winograd-domain weights (P, rows, k) of one layer and direction for tile size m, made on first use."""
 
-    def __init__(self, w_hwio: torch.Tensor, forward: bool):
-        self.w, self.forward, self.u = w_hwio, forward, {}
+    def __init__(self, w_hwio: torch.Tensor, forward: bool, device):
+        self.w, self.forward, self.u, self.device = w_hwio, forward, {}, torch.device(device)
 
     def __getitem__(self, m: int) -> torch.Tensor:
         if m not in self.u:
             g = self.w.permute(3, 2, 0, 1) if self.forward else self.w.flip(0, 1).permute(2, 3, 0, 1)
-            self.u[m] = _ops.winograd_weights(g, m)
+            self.u[m] = _ops.winograd_weights(g, m, self.device)        # on the MODEL's device, whichever is current
+            assert not torch.cuda.is_available() or self.u[m].device == _ops.canonical_device(self.device)
         return self.u[m]
 
 
@@ -185,8 +186,8 @@ class VGGParams:
                     # trunk actually asks for: all four for all 12 layers are 104x the weights = 6 GB and a third of
                     # the model's build time, and F(2x2,3x3) is hardly ever chosen since the small maps take the
                     # direct split-K kernel.
-                    L["u_fwd"] = _LazyWinograd(w, forward=True)
-                    L["u_bwd"] = _LazyWinograd(w, forward=False)
+                    L["u_fwd"] = _LazyWinograd(w, True, device)
+                    L["u_bwd"] = _LazyWinograd(w, False, device)
             self.layers.append(L)
         self.device = device
 

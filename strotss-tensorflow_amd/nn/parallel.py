@@ -71,6 +71,16 @@ def init_from_env(device_index=None):
     return dist.get_rank(), dist.get_world_size()
 
 
+def ranks_share_a_gpu() -> bool:
+    """True when the launcher put more ranks on this node than it has GPUs (LOCAL_WORLD_SIZE / WORLD_SIZE against
+    torch.cuda.device_count(), which does not touch the devices): a rehearsal of N ranks on one card.  The engine then
+    defaults to the sorted tap adjoint: next to ANOTHER process running the bf16x3 GEMM core one build of the
+    float-atomic kernel lost contributions (one process per GPU, the deployment, never shares)."""
+    import os
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return local > max(1, torch.cuda.device_count())
+
+
 def regions_for_rank(n_regions: int, rank: int, world: int) -> List[int]:
     """Round-robin ownership: region r belongs to rank r % world."""
     return list(range(rank, n_regions, world))
@@ -83,17 +93,6 @@ def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
-
-
-def sharded_pixel_gradient(region_grad: Callable[[int], torch.Tensor], n_regions: int, like: torch.Tensor,
-                           group=None) -> torch.Tensor:
-    """Sum of `region_grad(r)` (already scaled by 1/R) over all regions, computing only the regions
-    this rank owns and all-reducing the pixel gradient once."""
-    rank, world = world_info(group)
-    g = torch.zeros_like(like)
-    for r in regions_for_rank(n_regions, rank, world):
-        g += region_grad(r)
-    return allreduce_sum_(g, group)
 
 
 def aggregate_throughput(units_per_rank: float, elapsed_local: float, group=None, device=None):

@@ -333,6 +333,17 @@ def test_hypercol_scatter_window_drop(ops, sorted_scatter):
                 assert interior < 1e-5, (k, interior)              # clamping only ever touches the two edge rows ...
         if not drop:
             assert any(float((g_ - f[:, r0:r0 + g_.shape[1]]).abs().max()) > 1e-3 for g_, f, (r0, _) in zip(gw, full, wins))   # ... and does
+    # the GATHER always clamps into the window, whatever the descriptor's window_drop says (strotss_hip.h): a sample whose
+    # tap row lies outside must not come back with zeroed weights
+    import ctypes
+    outs = []
+    for drop in (True, False):
+        mt = _hip.make_maps(wmaps, divs, None, wins, window_drop=drop)
+        out = torch.zeros_like(gbuf)
+        _hip.check(_hip.lib().strotss_hypercol_gather(ctypes.byref(mt), dev(idx).data_ptr(), len(idx), 1, out.data_ptr(),
+                                                      out.shape[1], _hip.stream_ptr()), "hypercol_gather")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
 
 
 # ------------------------------------------------------------------ losses
@@ -549,23 +560,15 @@ def test_rmsprop_and_postprocess(ops):
         assert np.array_equal(got, ref), int((got != ref).sum())
 
 
-@pytest.mark.parametrize("variant", ["f32", "x3_in_registers", "x3_planes"])
-def test_fused_winograd_kernel_on_every_shape(variant):
+def test_fused_winograd_kernel_on_every_shape():
     """The fused F(4x4,3x3) kernel is chosen by a size policy that the small shapes of this file never meet; force it
     (STROTSS_WINO_FUSED=2 is read once per process) and run the Winograd parity tests again in a child process:
-    odd sizes, 32..512 channels, forward with bias/ReLU and pooled copy, data-gradient with and without ReLU mask.
-    Variants: the default f32-MFMA products; the same kernel with the products on the bf16 MFMA, operands split
-    exactly in registers (STROTSS_WINO_FUSED_PROD=x3); the separate pre-split-planes kernel
-    (csrc/winograd_fused_x3.hip, STROTSS_WINO_FUSED_X3=1) -- both measured slower, kept as tested alternatives."""
+    odd sizes, 32..512 channels, forward with bias/ReLU and pooled copy, data-gradient with and without ReLU mask."""
     import os, subprocess, sys
     if os.environ.get("STROTSS_WINO_FUSED") == "2":
         pytest.skip("already inside the forced run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, STROTSS_WINO_FUSED="2")
-    if variant == "x3_in_registers":
-        env["STROTSS_WINO_FUSED_PROD"] = "x3"
-    if variant == "x3_planes":
-        env["STROTSS_WINO_FUSED_X3"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_ops.py"), "-q", "-x", "-m", "gpu",
                           "-k", "test_conv_winograd_fwd_and_dgrad"], env=env, cwd=root, capture_output=True, text=True,
                          timeout=600)

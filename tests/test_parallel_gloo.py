@@ -59,7 +59,12 @@ def _worker(rank, world, port, out_dir):
         g, = torch.autograd.grad(loss, img)
         return g
 
-    gimg = parallel.sharded_pixel_gradient(region_grad, R, pyr[0])
+    # the engine's protocol (nn/engine.py `_pixel_gradient` + `_reduce`) restated on the oracle: this rank's regions
+    # only, then ONE all-reduce(sum) of the pixel gradient
+    gimg = torch.zeros_like(pyr[0])
+    for r in parallel.regions_for_rank(R, rank, world):
+        gimg += region_grad(r)
+    parallel.allreduce_sum_(gimg)
     # fold adjoint after the reduction: level-1 gradient = U^T gimg
     probe = torch.rand(pyr[1].shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
     value, elapsed = parallel.aggregate_throughput(10.0, 1.0 + rank)     # rank 1 is the slow one

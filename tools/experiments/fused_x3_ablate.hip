@@ -2,7 +2,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on [-DX3_NO_TRANSFORM|-DX3_NO_SPLIT|-DX3_NO_VSTORE|-DX3_NO_MFMA|-DX3_NO_U|-DX3_NO_RAW ...]
 //         -I strotss-tensorflow_amd/csrc tools/fused_x3_ablate.hip -o /tmp/fx3 && /tmp/fx3 [hw] [cin] [cout]
 // (results are wrong with any ablation defined; the plain build prints the kernel's time)
-#include "../strotss-tensorflow_amd/csrc/winograd_fused_x3.hip"
+#include "winograd_fused_x3.hip"
 #include <cstdio>
 #include <vector>
 int main(int argc, char** argv) {

@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void winograd43_in_x3_kernel(const float* __re
 __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __restrict__ Mw, int H, int W, int C4,
                                                              int TH, int TW, const float* __restrict__ bias,
                                                              const float* __restrict__ mask, int relu,
-                                                             float* __restrict__ out, int c4_shift) {
+                                                             float* __restrict__ out, int c4_shift, size_t Tstride) {
+  // Tstride: tiles per position plane of Mw (>= TH * TW: the streaming GEMM pads the planes to whole 128-row tiles)
   const size_t T = (size_t)TH * TW;
   const unsigned total = (unsigned)(T * C4);
   const f32x4* src = reinterpret_cast<const f32x4*>(Mw);
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
     for (int q = 0; q < 6; ++q) {
       f32x4 m[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) m[r] = src[((size_t)(r * 6 + q) * T + tile) * C4 + c];
+      for (int r = 0; r < 6; ++r) m[r] = src[((size_t)(r * 6 + q) * Tstride + tile) * C4 + c];
       s[0][q] = m[0] + m[1] + m[2] + m[3] + m[4];
       s[1][q] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
       s[2][q] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
@@ -326,15 +327,25 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
   if (T * (size_t)(max(cin, cout) / 4 + 8) >= (1ull << 32)) return STROTSS_ERANGE;     // 32-bit element indices in the transforms
   Workspace ws(workspace, workspace_bytes);
   float* V = ws.take<float>(36 * T * cin * 3 / 2);           // f32 V, or its x3 panels (3 bf16 per value)
-  float* Mw = ws.take<float>(36 * T * cout);
+  const size_t Tpad = (T + 127) / 128 * 128;                 // the streaming GEMM stores whole 128-row tiles
+  float* Mw = ws.take<float>(36 * Tpad * cout);
   if (!ws.ok()) return STROTSS_EINVAL;
   const size_t tout = T * (cout / 4);
+  size_t Tstride = T;
   int rc;
   if (x3) {
     const size_t tin = ((T + 7) / 8) * 8 * (cin / 4);
     hipLaunchKernelGGL(winograd43_in_x3_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
                        in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V), log2_or_minus1(cin / 32));
-    rc = st_gemm_x3_batched(V, Ux3, Mw, cout, (long long)T * cout, (int)T, cout, cin, 36, st, x3_min_tiles());
+    // two-kernel form: the GEMMs of all 36 positions and the output transform in ONE kernel, no M tensor
+    if (st_winograd43_gemm_out_enabled(T, cin, cout))
+      return st_winograd43_gemm_out(V, Ux3, T, cin, cout, h, w, TW, bias, mask, relu, out, st);
+    if (st_gemm_x3_stream_ok((int)T, cout, cin, 36)) {          // one persistent pipeline per CU over all 36 x tiles
+      Tstride = Tpad;
+      rc = st_gemm_x3_stream(V, Ux3, Mw, cout, (long long)Tpad * cout, (int)T, cout, cin, 36, st);
+    } else {
+      rc = st_gemm_x3_batched(V, Ux3, Mw, cout, (long long)T * cout, (int)T, cout, cin, 36, st, x3_min_tiles());
+    }
   } else {
     const size_t tin = T * (cin / 4);
     hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
@@ -344,7 +355,7 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
   }
   if (rc != 0) return rc;
   hipLaunchKernelGGL(winograd43_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
-                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out, log2_or_minus1(cout / 4));
+                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out, log2_or_minus1(cout / 4), Tstride);
   ST_LAUNCH_RET();
 }
 
@@ -432,7 +443,7 @@ int strotss_conv3x3_winograd_weights(const float* g_nk33, int n, int k, int tile
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m) {
   if (tile_m == 4) {
     const size_t T4 = (size_t)((h + 3) / 4) * ((w + 3) / 4);
-    return ws_slice(36 * T4 * cin * 3 / 2, sizeof(float)) + ws_slice(36 * T4 * cout, sizeof(float));
+    return ws_slice(36 * T4 * cin * 3 / 2, sizeof(float)) + ws_slice(36 * ((T4 + 127) / 128 * 128) * cout, sizeof(float));
   }
   const size_t T = (size_t)((h + 1) / 2) * ((w + 1) / 2);
   return ws_slice(16 * T * cin, sizeof(float)) + ws_slice(16 * T * cout, sizeof(float));

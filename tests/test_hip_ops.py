@@ -574,3 +574,38 @@ def test_fused_winograd_kernel_on_every_shape():
                          timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+def test_gemm_out_winograd_kernel_on_every_shape():
+    """The two-kernel F(4x4,3x3) form (csrc/winograd_gemm_out.hip: the 36 bf16x3 GEMMs with the output transform folded
+    in) is chosen for layers with at least 192 work items; force it on every shape it accepts (cin % 32 == 0,
+    cout % 64 == 0) together with the bf16x3 route, and run the Winograd parity tests again in a child process: partial
+    tile blocks, odd image sizes, bias / ReLU forward, data-gradient with and without the ReLU mask, 64..512 channels."""
+    import os, subprocess, sys
+    if os.environ.get("STROTSS_WINO_GEMM_OUT") == "2":
+        pytest.skip("already inside the forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STROTSS_WINO_GEMM_OUT="2", STROTSS_X3_MIN_TILES="1", STROTSS_X3_MIN_COUT="64", STROTSS_WINO_FUSED="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_ops.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "test_conv_winograd_fwd_and_dgrad"], env=env, cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
+def test_streaming_x3_gemm_on_every_shape():
+    """The persistent streaming form of the bf16x3 Winograd GEMMs (csrc/mfma_x3_stream.h: one workgroup per CU walks all
+    tiles of the 36 products with one continuous LDS-DMA pipeline, results leave during the next tile's K-steps) runs
+    where a layer has at least 512 tiles; force it on every shape it accepts (cout % 128 == 0, cin in {128, 256, 512}) and
+    run the Winograd parity tests in a child process: single-tile lists, clamped rows (T < 128), padded M planes."""
+    import os, subprocess, sys
+    if os.environ.get("STROTSS_X3_STREAM") == "2":
+        pytest.skip("already inside the forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STROTSS_X3_STREAM="2", STROTSS_X3_MIN_TILES="1", STROTSS_X3_MIN_COUT="64", STROTSS_WINO_FUSED="0",
+               STROTSS_WINO_GEMM_OUT="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_ops.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "test_conv_winograd_fwd_and_dgrad"], env=env, cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

@@ -49,6 +49,18 @@ const char* strotss_build_info(void);
  * practice: fold uses (add = residual, alpha = 1); make_laplacian uses (add = x, alpha = -1). */
 int strotss_resize_bilinear(const float* in, int ih, int iw, int c, float* out, int oh, int ow,
                             float alpha, const float* add, void* stream);
+/* fold_laplacian_pyramid (strotss_utils.py:159-163) of a 3-channel pyramid in ONE launch:
+ *   img = var[0] + up(var[1] + up(var[2] + ... up(var[n-1]))),   up = TF2 bilinear resize to the next finer level's size.
+ * Level k is (h[k], w[k], 3); every level at most as large as the one above it, halving or faster from level 1 on
+ * (what make_laplacian_pyramid builds); STROTSS_ERANGE otherwise (use strotss_resize_bilinear level by level).
+ * Same taps and arithmetic as n-1 calls of strotss_resize_bilinear(..., alpha = 1, add = var[k]). */
+#define STROTSS_MAX_LEVELS 8
+typedef struct {
+  int n_levels;
+  int h[STROTSS_MAX_LEVELS], w[STROTSS_MAX_LEVELS];
+  const float* var[STROTSS_MAX_LEVELS];
+} strotss_pyramid_t;
+int strotss_fold_pyramid(const strotss_pyramid_t* pyr, float* img, void* stream);
 /* adjoint of the above w.r.t. `in`: gin(ih,iw,c) = resize^T(gout(oh,ow,c)).  Deterministic
  * gather form (no atomics).  Replaces the TF gradient of strotss_utils.py:162. */
 int strotss_resize_bilinear_adjoint(const float* gout, int oh, int ow, int c, float* gin, int ih,
@@ -67,8 +79,10 @@ int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, c
 /* Generic layer, cin % 32 == 0, cout % 64 == 0:
  *   out(h,w,cout) = relu(conv3x3(in(h,w,cin)) + bias);  w_tok: (9, cout, cin), tap = dy*3+dx. */
 /* workspace (may be NULL; strotss_conv3x3_workspace_bytes(h, w, cin, cout) bytes, 0 for big maps): with it, layers of at
- * most 64 output tiles of 64 x 64 (the 4x4 ... 32x32 pixel maps of the small scales) split K over up to 256 workgroups
- * and a finish kernel adds the partial tiles in a fixed order (same result class, bitwise reproducible). */
+ * most 128 output tiles of 64 x 64 (the small maps of the 64 ... 256 px scales) split K over up to 256 workgroups and the
+ * last workgroup to arrive at a tile adds the partial tiles in a fixed order (same result class, bitwise reproducible).
+ * The first 4096 bytes of the workspace are arrival counters: they MUST BE ZERO before the first launch that uses the
+ * buffer (the kernels leave them zero); one workspace serves one stream at a time. */
 size_t strotss_conv3x3_workspace_bytes(int h, int w, int cin, int cout);
 int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float* w_tok,
                              const float* bias, int cout, float* out, void* workspace, size_t workspace_bytes,

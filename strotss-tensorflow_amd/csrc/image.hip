@@ -42,11 +42,81 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
           const float tl = r0[a + cc], tr = r0[b + cc], bl = r1[a + cc], br = r1[b + cc];
           const float top = tl + (tr - tl) * tx.lerp;
           const float bot = bl + (br - bl) * tx.lerp;
-          float v = alpha * (top + (bot - top) * ty.lerp);
+          float v = alpha * (top + (bot - top) * ty.lerp);        // fold_pyramid_kernel: the same expression with alpha = 1
           if (add) v += add[o + cc];
           out[o + cc] = v;
         }
     }
+  }
+}
+
+// ---------------------------------------------------------------- the whole Laplacian fold in ONE launch
+// fold_laplacian_pyramid (strotss_utils.py:159-163): ret = x[L-1]; for k = L-2 .. 0: ret = x[k] + up(ret).  As L-1 dependent
+// resize launches the fold costs ~5 us per level whatever the image size (5 of the 97 launches of a 64-px step); here one
+// workgroup owns a 32 x 32 tile of the image and RECOMPUTES the footprints of its tile in the coarser levels, bottom-up,
+// through two LDS buffers: the footprint of a region in the next level is [tap(lo).lo, tap(hi).hi] per axis, at most
+// 18 x 18, 11 x 11, 8 x 8 ... pixels for the halving pyramids make_laplacian_pyramid builds.  Same taps, same arithmetic
+// and same operation order per pixel as resize_bilinear_kernel<3>.
+#define FOLD_TILE 32
+#define FOLD_REGION 24                       // footprint side limit of levels >= 1 (checked on the host)
+struct FoldLevels { int n; int h[STROTSS_MAX_TENSORS], w[STROTSS_MAX_TENSORS]; const float* v[STROTSS_MAX_TENSORS]; };
+__device__ __forceinline__ float bilerp3(float tl, float tr, float bl, float br, float lx, float ly) {
+  const float top = tl + (tr - tl) * lx;
+  const float bot = bl + (br - bl) * lx;
+  return 1.0f * (top + (bot - top) * ly);     // alpha = 1 of resize_bilinear_kernel
+}
+__global__ __launch_bounds__(256) void fold_pyramid_kernel(FoldLevels p, float* __restrict__ img) {
+  __shared__ float buf[2][FOLD_REGION * FOLD_REGION * 3];
+  __shared__ int reg[STROTSS_MAX_TENSORS][4];                       // y0, y1, x0, x1 (inclusive) of every level's footprint
+  const int t = threadIdx.x;
+  if (t == 0) {
+    int y0 = blockIdx.y * FOLD_TILE, y1 = min(y0 + FOLD_TILE, p.h[0]) - 1;
+    int x0 = blockIdx.x * FOLD_TILE, x1 = min(x0 + FOLD_TILE, p.w[0]) - 1;
+    reg[0][0] = y0; reg[0][1] = y1; reg[0][2] = x0; reg[0][3] = x1;
+    for (int k = 1; k < p.n; ++k) {
+      const float sy = (float)p.h[k] / (float)p.h[k - 1], sx = (float)p.w[k] / (float)p.w[k - 1];
+      const int ny0 = axis_tap(y0, sy, p.h[k]).lo, ny1 = axis_tap(y1, sy, p.h[k]).hi;
+      const int nx0 = axis_tap(x0, sx, p.w[k]).lo, nx1 = axis_tap(x1, sx, p.w[k]).hi;
+      y0 = ny0; y1 = ny1; x0 = nx0; x1 = nx1;
+      reg[k][0] = y0; reg[k][1] = y1; reg[k][2] = x0; reg[k][3] = x1;
+    }
+  }
+  __syncthreads();
+  // coarsest level: a copy of its footprint
+  {
+    const int k = p.n - 1, y0 = reg[k][0], x0 = reg[k][2], rh = reg[k][1] - y0 + 1, rw = reg[k][3] - x0 + 1;
+    float* dst = buf[k & 1];
+    for (int e = t; e < rh * rw; e += 256) {
+      const int ry = e / rw, rx = e - ry * rw;
+      const float* s = p.v[k] + ((size_t)(y0 + ry) * p.w[k] + x0 + rx) * 3;
+      dst[e * 3 + 0] = s[0]; dst[e * 3 + 1] = s[1]; dst[e * 3 + 2] = s[2];
+    }
+  }
+  __syncthreads();
+  for (int k = p.n - 2; k >= 0; --k) {
+    const int y0 = reg[k][0], x0 = reg[k][2], rh = reg[k][1] - y0 + 1, rw = reg[k][3] - x0 + 1;
+    const int cy0 = reg[k + 1][0], cx0 = reg[k + 1][2], cw = reg[k + 1][3] - cx0 + 1;
+    const int ih = p.h[k + 1], iw = p.w[k + 1];
+    const float sy = (float)ih / (float)p.h[k], sx = (float)iw / (float)p.w[k];
+    const float* src = buf[(k + 1) & 1];
+    float* dst = k == 0 ? nullptr : buf[k & 1];
+    for (int e = t; e < rh * rw; e += 256) {
+      const int ry = e / rw, rx = e - ry * rw;
+      const int oy = y0 + ry, ox = x0 + rx;
+      const AxisTap ty = axis_tap(oy, sy, ih), tx = axis_tap(ox, sx, iw);
+      const float* r0 = src + (size_t)(ty.lo - cy0) * cw * 3;
+      const float* r1 = src + (size_t)(ty.hi - cy0) * cw * 3;
+      const int a = (tx.lo - cx0) * 3, b = (tx.hi - cx0) * 3;
+      const size_t o = ((size_t)oy * p.w[k] + ox) * 3;
+      const float* add = p.v[k] + o;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = bilerp3(r0[a + c], r0[b + c], r1[a + c], r1[b + c], tx.lerp, ty.lerp);
+        v += add[c];
+        if (k == 0) img[o + c] = v; else dst[e * 3 + c] = v;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -405,6 +475,27 @@ int strotss_resize_bilinear(const float* in, int ih, int iw, int c, float* out, 
   else
     hipLaunchKernelGGL(resize_bilinear_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, in, ih, iw, c, out, oh, ow, sy, sx,
                        alpha, add);
+  ST_LAUNCH_RET();
+}
+
+int strotss_fold_pyramid(const strotss_pyramid_t* pyr, float* img, void* stream) {
+  ST_CHECK_ARG(pyr && img && pyr->n_levels >= 2 && pyr->n_levels <= STROTSS_MAX_TENSORS, STROTSS_EINVAL);
+  FoldLevels p;
+  p.n = pyr->n_levels;
+  for (int k = 0; k < p.n; ++k) {
+    ST_CHECK_ARG(pyr->var[k] && pyr->h[k] > 0 && pyr->w[k] > 0, STROTSS_EINVAL);
+    p.h[k] = pyr->h[k]; p.w[k] = pyr->w[k]; p.v[k] = pyr->var[k];
+  }
+  // footprint sides of a 32-pixel tile, level by level, against the LDS buffers: worst case over tile positions is
+  // ceil(side * scale) + 2 per axis; shrinking pyramids only (every level at most as large as the one above it)
+  int sy = FOLD_TILE, sx = FOLD_TILE;
+  for (int k = 1; k < p.n; ++k) {
+    ST_CHECK_ARG(p.h[k] <= p.h[k - 1] && p.w[k] <= p.w[k - 1], STROTSS_ERANGE);
+    sy = (int)((long long)sy * p.h[k] / p.h[k - 1]) + 3; sx = (int)((long long)sx * p.w[k] / p.w[k - 1]) + 3;
+    ST_CHECK_ARG(sy <= FOLD_REGION && sx <= FOLD_REGION, STROTSS_ERANGE);
+  }
+  hipLaunchKernelGGL(fold_pyramid_kernel, dim3((unsigned)cdiv(p.w[0], FOLD_TILE), (unsigned)cdiv(p.h[0], FOLD_TILE)), dim3(256),
+                     0, (hipStream_t)stream, p, img);
   ST_LAUNCH_RET();
 }
 

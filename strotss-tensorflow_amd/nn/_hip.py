@@ -35,6 +35,10 @@ class MapsT(C.Structure):
                 ("window_drop", C.c_int)]
 
 
+class PyramidT(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("h", C.c_int * 8), ("w", C.c_int * 8), ("var", C.c_void_p * 8)]
+
+
 class TensorsT(C.Structure):
     _fields_ = [("n_tensors", C.c_int),
                 ("var", C.c_void_p * MAX_TENSORS), ("rms", C.c_void_p * MAX_TENSORS),
@@ -47,6 +51,7 @@ SIGNATURES = {
     "strotss_abi_version": (_I, []),
     "strotss_build_info": (C.c_char_p, []),
     "strotss_resize_bilinear": (_I, [_P, _I, _I, _I, _P, _I, _I, _F, _P, _P]),
+    "strotss_fold_pyramid": (_I, [C.POINTER(PyramidT), _P, _P]),
     "strotss_resize_bilinear_adjoint": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "strotss_conv3x3_c3_fwd": (_I, [_P, _I, _I, _P, _P, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
     "strotss_conv3x3_workspace_bytes": (_Z, [_I, _I, _I, _I]),

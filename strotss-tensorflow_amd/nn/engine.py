@@ -47,6 +47,26 @@ def extract_features(params: VGGParams, image: torch.Tensor) -> List[torch.Tenso
     return [img] + [t.clone() for t in trunk.forward(img)]
 
 
+class _Capture:
+    """`torch.cuda.graph(g)` without its gc.collect() + torch.cuda.empty_cache() (12 ms per capture, five captures per run:
+    the step allocates nothing, so there is no allocator state to tidy up before a capture)."""
+
+    def __init__(self, graph: "torch.cuda.CUDAGraph", stream: "torch.cuda.Stream"):
+        self.graph, self.stream = graph, stream
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        self.graph.capture_begin()
+        return self
+
+    def __exit__(self, *exc):
+        self.graph.capture_end()
+        self._ctx.__exit__(*exc)
+        return False
+
+
 class StepEngine:
     """One scale of the coarse-to-fine loop: owns the 6 pyramid variables and their RMSprop slots.
 
@@ -79,6 +99,8 @@ class StepEngine:
         self.sizes = [(int(v.shape[1]), int(v.shape[2])) for v in self.variables]
         # fold temporaries: f[k] = v[k] + up(f[k+1]); f[0] is the image
         self.fold = [torch.empty_like(v) for v in self.variables[:-1]]
+        import os as _os
+        self._fold_one_launch = None if _os.environ.get("STROTSS_FOLD_ONE_LAUNCH", "1") != "0" else False
         # image strips (nn/parallel.py): the trunk covers rows [win0, win1) only; everything else is full-size
         self.strips = strips
         win0, win1 = (strips.win0, strips.win1) if strips is not None else (0, h)
@@ -155,6 +177,11 @@ class StepEngine:
     # ------------------------------------------------------------------ pieces of the step
     def fold_forward(self) -> torch.Tensor:
         """img = fold_laplacian_pyramid(variables)   (strotss_utils.py:159-163)"""
+        if self._fold_one_launch is not False:            # one launch for the whole fold (csrc/image.hip: fold_pyramid_kernel)
+            if _ops.fold_pyramid(self.variables, self.fold[0]) is not None:
+                self._fold_one_launch = True
+                return self.fold[0]
+            self._fold_one_launch = False                 # a pyramid shape the kernel does not take: level by level
         t = self.variables[-1]
         for k in range(len(self.variables) - 2, -1, -1):
             hk, wk = self.sizes[k]
@@ -344,14 +371,14 @@ class StepEngine:
         torch.cuda.synchronize()
         g, post = torch.cuda.CUDAGraph(), None
         if self.world > 1:
-            with torch.cuda.graph(g):
+            with _Capture(g, side):
                 self._pixel_gradient(self._graph_idx)
             post = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(post):
+            with _Capture(post, side):
                 self._fold_adjoint()
                 self.apply_gradients()
         else:
-            with torch.cuda.graph(g):
+            with _Capture(g, side):
                 self._pixel_gradient(self._graph_idx)
                 self._fold_adjoint()
                 self.apply_gradients()

@@ -609,3 +609,28 @@ def test_streaming_x3_gemm_on_every_shape():
                          timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (170, 256), (683, 1024), (1024, 1024), (42, 64), (5, 7), (1, 1), (33, 2)])
+def test_fold_pyramid_one_launch_equals_level_by_level(ops, hw):
+    """strotss_fold_pyramid (one launch, every tile recomputes its coarse footprints through LDS) against the fold as
+    five dependent resize launches and against the float64 oracle (strotss_utils.py:159-163): same taps, same arithmetic."""
+    from nn import strotss_utils as SU
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 7 + w)
+    img = torch.rand(1, h, w, 3, generator=g, dtype=torch.float64)
+    pyr64 = O.make_laplacian_pyramid(img)
+    # perturb the levels independently so that the fold is not just the image again
+    pyr64 = [p + 0.1 * torch.randn(p.shape, generator=g, dtype=torch.float64) for p in pyr64]
+    pyr = [dev(p) for p in pyr64]
+    out = torch.full((1, h, w, 3), float("nan"), device="cuda")
+    got = ops.fold_pyramid(pyr, out)
+    assert got is not None, "a halving pyramid must be taken by the one-launch kernel"
+    t = pyr[-1]
+    for k in range(len(pyr) - 2, -1, -1):
+        t = ops.resize_bilinear(t, int(pyr[k].shape[1]), int(pyr[k].shape[2]), 1.0, pyr[k])
+    assert torch.equal(got, t), float((got - t).abs().max())
+    ref = O.fold_laplacian_pyramid(pyr64).numpy()
+    assert np.abs(got.cpu().numpy() - ref).max() < 3e-6 * max(1.0, np.abs(ref).max())
+    # a pyramid that does not shrink is refused (the caller then folds level by level)
+    assert ops.fold_pyramid([pyr[-1], pyr[0]], torch.empty_like(pyr[-1])) is None or h * w == 1

@@ -79,10 +79,11 @@ int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, c
 /* Generic layer, cin % 32 == 0, cout % 64 == 0:
  *   out(h,w,cout) = relu(conv3x3(in(h,w,cin)) + bias);  w_tok: (9, cout, cin), tap = dy*3+dx. */
 /* workspace (may be NULL; strotss_conv3x3_workspace_bytes(h, w, cin, cout) bytes, 0 for big maps): with it, layers of at
- * most 128 output tiles of 64 x 64 (the small maps of the 64 ... 256 px scales) split K over up to 256 workgroups and the
- * last workgroup to arrive at a tile adds the partial tiles in a fixed order (same result class, bitwise reproducible).
- * The first 4096 bytes of the workspace are arrival counters: they MUST BE ZERO before the first launch that uses the
- * buffer (the kernels leave them zero); one workspace serves one stream at a time. */
+ * most 128 output tiles of 64 x 64 (the small maps of the 64 ... 256 px scales) split K over up to 256 workgroups
+ * and a finish kernel adds the partial tiles in a fixed order (same result class, bitwise reproducible).
+ * (Round 3 measured the finish INSIDE the split-K kernel -- last workgroup to arrive at a tile, agent-scope release /
+ * ticket / acquire: 1.32 ms per 64-px step against 0.835 ms with the finish launch; 256 workgroups each writing back
+ * their XCD's L2 cost far more than the 24 kernel boundaries they replace.  Not kept.) */
 size_t strotss_conv3x3_workspace_bytes(int h, int w, int cin, int cout);
 int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float* w_tok,
                              const float* bias, int cout, float* out, void* workspace, size_t workspace_bytes,

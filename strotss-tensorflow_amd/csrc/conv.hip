@@ -229,21 +229,11 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_pipe_kernel(const float*
 // 64 x 64 output tiles and the three-kernel Winograd form is three dependent, latency-bound launches of 5-9 us each;
 // here `nsplit` workgroups per tile take consecutive ranges of the 9 * Cin / 32 K-steps (a 512 -> 512 layer on 4 x 4
 // pixels: 8 tiles x 32 splits = 256 workgroups, each streams 37 KB of weights), write their partial tiles, and the
-// LAST workgroup to arrive at a tile adds them in split order (fixed: bitwise reproducible) with bias / ReLU / mask.
-// Round 3: the finish used to be a second launch; at the 64-px scale 24 of a step's 97 dependent launches were finish
-// kernels of 5 us each.  Now: partial tile -> every wave drains its stores -> barrier -> one lane: agent-scope release,
-// ticket on the tile's counter (relaxed, agent scope); the workgroup that draws nsplit - 1 is the finisher: agent-scope
-// acquire by the same lane, barrier, plain 16-byte loads of all partial tiles (MI355X_MICROARCH.md, "Valid forms": the
-// counter form of the hand-off; correct for any placement of a tile's splits).  The finisher leaves the counter at zero
-// for the next launch: the counters (first SPLITK_COUNTER_BYTES of the workspace) must be zero before the FIRST launch.
-#define SPLITK_COUNTER_BYTES 4096
+// finish kernel adds them in split order (fixed: bitwise reproducible) with bias / ReLU / mask.
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_splitk_kernel(const float* __restrict__ in, int H, int W, int Cin,
                                                                       const float* __restrict__ wt, int Cout, int nsplit,
-                                                                      float* __restrict__ part, int* __restrict__ counters,
-                                                                      const f32x4* __restrict__ bias,
-                                                                      const f32x4* __restrict__ mask, int relu,
-                                                                      f32x4* __restrict__ out, int accumulate) {
+                                                                      float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   const int HW = H * W;
   const unsigned gx = Cout / Cfg::BN, gy = (HW + Cfg::BM - 1) / Cfg::BM, ntile = gx * gy;
@@ -274,42 +264,6 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_splitk_kernel(const floa
         const int p = m0 + map.row(im, reg);
         if (p < HW) P[(size_t)p * Cout + n0 + map.colof(in_)] = acc[im][in_][reg];
       }
-  if (!counters) return;                                          // a finish LAUNCH follows (A/B switch)
-  // ---- hand-off: am I the last split of this tile?
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave
-  __syncthreads();
-  int* flag = reinterpret_cast<int*>(lds);                        // the ring is idle now (one LDS object: no second array)
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ticket = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = ticket == nsplit - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-    }
-    *flag = last;
-  }
-  __syncthreads();
-  if (!*flag) return;
-  // ---- finisher: out = epilogue(sum over the splits, in split order) for the tile's rows x 64 channels
-  const size_t total4 = (size_t)HW * Cout / 4;
-  const int cout4 = Cout >> 2, rows = min(Cfg::BM, HW - m0);
-  const f32x4* part4 = reinterpret_cast<const f32x4*>(part);
-  for (int e = threadIdx.x; e < rows * (Cfg::BN / 4); e += Cfg::NT) {
-    const int r = e / (Cfg::BN / 4), c4 = e - r * (Cfg::BN / 4);
-    const size_t o = (size_t)(m0 + r) * cout4 + (n0 >> 2) + c4;
-    f32x4 v = part4[o];
-    for (int s = 1; s < nsplit; ++s) v = v + part4[(size_t)s * total4 + o];
-    if (bias) v = v + bias[(n0 >> 2) + c4];
-    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    if (mask) {
-      const f32x4 m = mask[o];
-      v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f; v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
-    }
-    out[o] = accumulate ? out[o] + v : v;
-  }
 }
 // out = epilogue(sum_s part[s]): + bias, ReLU (forward) or * (mask > 0) (data-gradient); 4 channels per thread
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const f32x4* __restrict__ part, int nsplit, size_t total4,
@@ -389,23 +343,15 @@ int conv_dispatch(const float* in, int H, int W, int Cin, const float* wt, const
                   int accumulate = 0) {
   const int64_t M = (int64_t)H * W;
   const int nsplit = conv_splits(H, W, Cin, Cout);
-  if (nsplit && workspace && workspace_bytes >= SPLITK_COUNTER_BYTES + (size_t)nsplit * M * Cout * sizeof(float)) {
+  if (nsplit && workspace && workspace_bytes >= (size_t)nsplit * M * Cout * sizeof(float)) {
     using Cfg = PipeCfg<64, 64, 2, 2>;
-    const unsigned tiles = (unsigned)(cdiv(M, 64) * (Cout / 64));                 // <= 128 (conv_splits): 512 B of counters
-    float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + SPLITK_COUNTER_BYTES);
-    static const int separate = [] { const char* e = getenv("STROTSS_SPLITK_FINISH_KERNEL"); return e ? atoi(e) : 0; }();
-    if (separate) {                      // round 2's form, for A/B runs: partial tiles, then a finish LAUNCH
-      hipLaunchKernelGGL((conv3x3_mfma_splitk_kernel<Cfg>), dim3(tiles * nsplit), dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, Cout,
-                         nsplit, part, (int*)nullptr, (const f32x4*)nullptr, (const f32x4*)nullptr, 0, (f32x4*)nullptr, 0);
-      const size_t total4 = (size_t)M * Cout / 4;
-      hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)min((size_t)2048, (total4 + 255) / 256)), dim3(256), 0, s,
-                         (const f32x4*)part, nsplit, total4, Cout / 4, (const f32x4*)bias, (const f32x4*)mask, relu,
-                         (f32x4*)out, accumulate);
-      ST_LAUNCH_RET();
-    }
+    const unsigned tiles = (unsigned)(cdiv(M, 64) * (Cout / 64));
     hipLaunchKernelGGL((conv3x3_mfma_splitk_kernel<Cfg>), dim3(tiles * nsplit), dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, Cout,
-                       nsplit, part, static_cast<int*>(workspace), (const f32x4*)bias, (const f32x4*)mask, relu, (f32x4*)out,
-                       accumulate);
+                       nsplit, (float*)workspace);
+    const size_t total4 = (size_t)M * Cout / 4;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)min((size_t)2048, (total4 + 255) / 256)), dim3(256), 0, s,
+                       (const f32x4*)workspace, nsplit, total4, Cout / 4, (const f32x4*)bias, (const f32x4*)mask, relu,
+                       (f32x4*)out, accumulate);
     ST_LAUNCH_RET();
   }
   if (accumulate) return STROTSS_EINVAL;              // only the split-K form adds to its output
@@ -829,8 +775,7 @@ int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, c
 
 size_t strotss_conv3x3_workspace_bytes(int h, int w, int cin, int cout) {
   if (h <= 0 || w <= 0 || cin <= 0 || cin % 32 || cout <= 0 || cout % 64) return 0;
-  const int n = conv_splits(h, w, cin, cout);
-  return n ? SPLITK_COUNTER_BYTES + (size_t)n * h * w * cout * sizeof(float) : 0;
+  return (size_t)conv_splits(h, w, cin, cout) * h * w * cout * sizeof(float);
 }
 
 int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float* w_tok, const float* bias,

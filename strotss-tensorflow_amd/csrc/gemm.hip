@@ -433,7 +433,10 @@ struct X3Mirror {       // writes the transpose of the workgroup's tile through 
 // 128 per batch entry (strideC >= round_up(M, 128) * ldc): every store is unconditional.  Returns 1 when the shape does
 // not qualify (the caller takes the per-tile form).
 bool st_gemm_x3_stream_ok(int M, int N, int K, int batch) {
-  static const int on = [] { const char* v = getenv("STROTSS_X3_STREAM"); return v ? atoi(v) : 1; }();
+  // default OFF: measured on block3 / block4 at 1024 px the stream takes 138 us against the per-tile form's 125 us -- its
+  // 151 MB of result stores share the in-order vmcnt with the LDS-DMA and the layer is HBM-bound either way (without its
+  // stores the same kernel runs in 82 us).  STROTSS_X3_STREAM=1: where a layer has >= 512 tiles; 2: everywhere.
+  static const int on = [] { const char* v = getenv("STROTSS_X3_STREAM"); return v ? atoi(v) : 0; }();
   if (!on || N % 128 != 0 || !(K == 128 || K == 256 || K == 512)) return false;
   const long long tiles = (long long)cdiv(M, 128) * (N / 128) * batch;
   // fewer than two tiles per CU: the list is too short to keep 256 pipelines full (block5 at 1024 px: 288 tiles)

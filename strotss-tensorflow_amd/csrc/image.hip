@@ -491,7 +491,8 @@ int strotss_fold_pyramid(const strotss_pyramid_t* pyr, float* img, void* stream)
   int sy = FOLD_TILE, sx = FOLD_TILE;
   for (int k = 1; k < p.n; ++k) {
     ST_CHECK_ARG(p.h[k] <= p.h[k - 1] && p.w[k] <= p.w[k - 1], STROTSS_ERANGE);
-    sy = (int)((long long)sy * p.h[k] / p.h[k - 1]) + 3; sx = (int)((long long)sx * p.w[k] / p.w[k - 1]) + 3;
+    sy = min(p.h[k], (int)((long long)sy * p.h[k] / p.h[k - 1]) + 3);
+    sx = min(p.w[k], (int)((long long)sx * p.w[k] / p.w[k - 1]) + 3);
     ST_CHECK_ARG(sy <= FOLD_REGION && sx <= FOLD_REGION, STROTSS_ERANGE);
   }
   hipLaunchKernelGGL(fold_pyramid_kernel, dim3((unsigned)cdiv(p.w[0], FOLD_TILE), (unsigned)cdiv(p.h[0], FOLD_TILE)), dim3(256),

@@ -99,7 +99,7 @@ def conv3x3_relu_fwd(x, w_tok, bias, out=None):
     if out is None:
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
     nb = _hip.lib().strotss_conv3x3_workspace_bytes(h, w, cin, cout)
-    ws = workspaces.get("conv_splitk", nb, x.device, zero=True) if nb else None
+    ws = workspaces.get("conv_splitk", nb, x.device) if nb else None
     check(_hip.lib().strotss_conv3x3_relu_fwd(ptr(x), h, w, cin, ptr(w_tok), ptr(bias), cout, ptr(out), ptr(ws), nb,
                                               stream_ptr()), "conv3x3_relu_fwd")
     return out
@@ -115,7 +115,7 @@ def conv3x3_dgrad(gout, w_tik, cin, act_in=None, out=None, accumulate=False):
     if out is None:
         out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
     nb = _hip.lib().strotss_conv3x3_workspace_bytes(h, w, cout, cin)
-    ws = workspaces.get("conv_splitk", nb, gout.device, zero=True) if nb else None
+    ws = workspaces.get("conv_splitk", nb, gout.device) if nb else None
     check(_hip.lib().strotss_conv3x3_dgrad(ptr(gout), h, w, cout, ptr(w_tik), cin, ptr(act_in), ptr(out), int(accumulate),
                                            ptr(ws), nb, stream_ptr()), "conv3x3_dgrad")
     return out
@@ -344,13 +344,11 @@ class _WsCache:
     def __init__(self):
         self.bufs = {}
 
-    def get(self, tag: str, nbytes: int, device, zero: bool = False) -> torch.Tensor:
-        """zero: a fresh buffer starts zero-filled (the split-K convolution keeps its arrival counters at the front of
-        its workspace and leaves them zero after every launch)."""
+    def get(self, tag: str, nbytes: int, device) -> torch.Tensor:
         key = (tag, str(device))
         b = self.bufs.get(key)
         if b is None or b.numel() < nbytes:
-            b = (torch.zeros if zero else torch.empty)(max(nbytes, 256), dtype=torch.uint8, device=device)
+            b = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
             self.bufs[key] = b
         return b
 

@@ -18,9 +18,13 @@ A bare `python bench.py --gpus N` (no torchrun around it) starts the N ranks its
 `python -m torch.distributed.run` as a CHILD process before anything touches the GPU and exits with the child's code.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      : the dominant kernel (3x3 conv implicit GEMM on the fp32 MFMA): algorithmic FLOP of
-                  all conv launches of one step / their summed HIP-event time, vs the 157.3 TFLOP/s
-                  dense f32 MFMA peak (MI355X_MICROARCH.md);
+  roofline      : the kernel class with the largest share of the step (at 1024 px: the fused F(4x4,3x3) Winograd kernel
+                  on the f32 MFMA) against ITS bound, from the routing the library actually took per layer and direction
+                  (strotss_conv3x3_winograd_route); `by_path` holds all three classes, each against its own bound:
+                  f32-MFMA kernels vs 157.3 TFLOP/s, bf16x3 GEMMs vs 2500 / 6 TFLOP/s, Winograd transform kernels vs
+                  8 TB/s; `blended` keeps rounds 1-2's all-conv-launches figure, labelled as a blend; `traffic` = HBM
+                  bytes per launch of the dominant kernel from two `rocprofv3 --pmc` child passes of THIS run (falls back
+                  to the committed profile, and says so, when rocprofv3 is missing);
   roofline_pairwise : the cosine cost-matrix GEMM (N x N x D) the metric names, same method;
   cpu_baseline  : the oracle (oracle/strotss_oracle.py, fp32 torch-CPU restatement of the
                   reference) timed on the host cores on a bounded sample of the same workload;
@@ -120,11 +124,11 @@ def run_steps(eng, idx, first, count):
 
 FAMILIES = ["conv3x3_relu_fwd", "conv3x3_dgrad", "conv3x3_winograd_fwd", "conv3x3_winograd_dgrad", "selfsim_fwd_bwd",
             "remd_cos_fwd_bwd", "moment_fwd_bwd", "palette_remd_fwd_bwd", "hypercol_scatter", "maxpool2_bwd", "maxpool2_fwd",
-            "conv3x3_c3_fwd", "conv3x3_c3_dgrad", "rmsprop_step", "resize_bilinear", "resize_bilinear_adjoint",
+            "conv3x3_c3_fwd", "conv3x3_c3_dgrad", "rmsprop_step", "resize_bilinear", "fold_pyramid", "resize_bilinear_adjoint",
             "loss_section"]
 
 
-def time_kernel_families(eng, idx, steps=7):
+def time_kernel_families(eng, idx, steps=7, with_sites=False):
     """HIP-event time of every conv launch, of the loss entry points and of the HBM-bound families, on the stream the
     kernels are launched on (torch's current stream).  Eager launches (events cannot sit between the nodes of a replayed
     graph): one untimed eager step first, then `steps` timed ones; per call site (family, ordinal of the call inside the
@@ -179,12 +183,114 @@ def time_kernel_families(eng, idx, steps=7):
         if step == 0:
             continue                          # the eager warm-up step
         per_site.setdefault((name, ordinal), []).append(e0.elapsed_time(e1))
-    out = {}
-    for (name, _), ts in per_site.items():
+    out, sites = {}, {}
+    for (name, ordinal), ts in per_site.items():
         med = float(np.median(ts))
+        sites[(name, ordinal)] = med
         t, c = out.get(name, (0.0, 0))
         out[name] = (t + med, c + 1)
-    return {k: {"ms_per_step": v[0], "launches_per_step": v[1]} for k, v in out.items()}
+    fam = {k: {"ms_per_step": v[0], "launches_per_step": v[1]} for k, v in out.items()}
+    return (fam, sites) if with_sites else fam
+
+
+ROUTE_NAMES = {0: "F(2x2,3x3): winograd_in_kernel -> gemm_kc_pipe_kernel x16 (f32 MFMA) -> winograd_out_kernel",
+               1: "winograd43_fused_kernel (F(4x4,3x3), transforms + 36 products on chip, f32 MFMA)",
+               2: "winograd43_in_kernel -> gemm_kc_pipe_kernel x36 (f32 MFMA) -> winograd43_out_kernel",
+               3: "winograd43_in_x3_kernel -> gemm_x3_kernel<X3CfgK16<3>> x36 (bf16x3, 128x128 tiles) -> winograd43_out_kernel",
+               4: "winograd43_in_x3_kernel -> gemm_x3_kernel<X3Cfg<64>> x36 (bf16x3, 64x64 tiles) -> winograd43_out_kernel",
+               5: "winograd43_in_x3_kernel -> gemm_x3_stream_kernel (bf16x3, persistent) -> winograd43_out_kernel",
+               6: "winograd43_in_x3_kernel -> winograd43_gemm_out_kernel (bf16x3 GEMMs + output transform)",
+               -1: "conv3x3_mfma_pipe_kernel / conv3x3_mfma_splitk_kernel (direct 3x3, f32 MFMA)"}
+
+
+def conv_path_breakdown(eng, idx, params, sites7):
+    """What the 12 generic conv layers of a step ACTUALLY ran (route per layer and direction from the library's own policy,
+    strotss_conv3x3_winograd_route) and where their time went, in three classes, each against its own bound:
+    f32-MFMA kernels (fused Winograd kernel, f32 GEMMs, direct conv) vs the dense f32 MFMA peak; bf16x3 GEMMs vs the dense
+    bf16 peak / 6; transform kernels vs the HBM peak.  Three-kernel layers are split by timing the same eager steps with
+    the library's stage mask at 1 (input transform only), 3 (+ GEMMs) and 7 (all): in = t1, GEMMs = t3 - t1, out = t7 - t3."""
+    from nn import _hip, _ops
+    lib = _hip.lib()
+    tr = eng.trunk
+    old = lib.strotss_debug_winograd_stages(3)
+    try:
+        _, sites3 = time_kernel_families(eng, idx, steps=5, with_sites=True)
+        lib.strotss_debug_winograd_stages(1)
+        _, sites1 = time_kernel_families(eng, idx, steps=5, with_sites=True)
+    finally:
+        lib.strotss_debug_winograd_stages(old)
+    macs = {0: 9.0, 2: 4.0, 4: 2.25}
+    cls = {"f32_mfma": {"gflop": 0.0, "ms": 0.0, "kernels": set()}, "bf16x3_gemm": {"gflop": 0.0, "ms": 0.0, "kernels": set()},
+           "transforms": {"GB": 0.0, "ms": 0.0, "kernels": set()}}
+    per_layer = []
+    ordinals = {}
+    plan = [st for st in tr.plan if st[0] == 'conv' and params.layers[st[1]]["cin"] != 3]
+    for direction in ("fwd", "dgrad"):
+        for st in (plan if direction == "fwd" else reversed(plan)):
+            _, li, (kind, _si) = st
+            L, a, t = params.layers[li], tr.acts[li], tr.wtile[li]
+            h, w = int(a.shape[1]), int(a.shape[2])
+            cin, cout = (L["cin"], L["cout"]) if direction == "fwd" else (L["cout"], L["cin"])
+            name = {("fwd", True): "conv3x3_winograd_fwd", ("fwd", False): "conv3x3_relu_fwd",
+                    ("dgrad", True): "conv3x3_winograd_dgrad", ("dgrad", False): "conv3x3_dgrad"}[(direction, t != 0)]
+            site = (name, ordinals.get(name, 0))
+            ordinals[name] = site[1] + 1
+            t7 = sites7.get(site)
+            if t7 is None:
+                continue
+            flop = 2.0 * macs[t] * cin * cout * h * w
+            if t == 0:
+                route = -1
+            else:
+                u = L["u_fwd" if direction == "fwd" else "u_bwd"][t]
+                route = int(lib.strotss_conv3x3_winograd_route(h, w, cin, cout, t, int(_ops.winograd_packed(u) is not None),
+                                                               int(_ops.winograd_x3(u, h, w) is not None)))
+            rec = {"layer": L["name"], "dir": direction, "hw": [h, w], "cin": cin, "cout": cout, "route": route,
+                   "ms": round(t7, 4)}
+            if route in (-1, 1):
+                cls["f32_mfma"]["gflop"] += flop / 1e9; cls["f32_mfma"]["ms"] += t7
+                cls["f32_mfma"]["kernels"].add(ROUTE_NAMES[route])
+            else:
+                t1, t3 = sites1.get(site, 0.0), sites3.get(site, 0.0)
+                t_in, t_gemm, t_out = t1, max(t3 - t1, 0.0), max(t7 - t3, 0.0)
+                m = t + 2
+                T = -(-h // t) * -(-w // t)
+                x3 = route in (3, 4, 5, 6)
+                v_bytes = m * m * T * cin * 4.0 * (1.5 if x3 else 1.0)
+                m_bytes = m * m * T * cout * 4.0
+                x_in, x_out = h * w * cin * 4.0, h * w * cout * 4.0
+                has_mask = direction == "dgrad" and kind == "conv"
+                tb = x_in + v_bytes                                     # input transform: reads X, writes V
+                if route != 6:
+                    tb += m_bytes + x_out * (2.0 if has_mask else 1.0)  # output transform: reads M (+ mask), writes X
+                    cls["transforms"]["ms"] += t_in + t_out
+                else:                                                   # output transform lives in the GEMM kernel
+                    cls["transforms"]["ms"] += t_in
+                    t_gemm = max(t7 - t1, 0.0)
+                cls["transforms"]["GB"] += tb / 1e9
+                cls["transforms"]["kernels"].add("winograd43_in_x3_kernel" if x3 else ("winograd43_in_kernel" if t == 4 else "winograd_in_kernel"))
+                if route != 6:
+                    cls["transforms"]["kernels"].add("winograd43_out_kernel" if t == 4 else "winograd_out_kernel")
+                key = "bf16x3_gemm" if x3 else "f32_mfma"
+                cls[key]["gflop"] += flop / 1e9; cls[key]["ms"] += t_gemm
+                cls[key]["kernels"].add(ROUTE_NAMES[route])
+                rec.update({"in_ms": round(t_in, 4), "gemm_ms": round(t_gemm, 4), "out_ms": round(t_out, 4)})
+            per_layer.append(rec)
+    out = {}
+    for k, peak, unit in (("f32_mfma", F32_MFMA_PEAK_TFLOPS, "TFLOP/s"), ("bf16x3_gemm", BF16_MFMA_PEAK_TFLOPS / 6.0, "TFLOP/s")):
+        c = cls[k]
+        if c["ms"] > 0:
+            ach = c["gflop"] / c["ms"]
+            out[k] = {"kernels": sorted(c["kernels"]), "executed_gflop_per_step": round(c["gflop"], 1),
+                      "ms_per_step": round(c["ms"], 3), "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit,
+                      "frac": round(ach / peak, 4)}
+    c = cls["transforms"]
+    if c["ms"] > 0:
+        rate = c["GB"] / (c["ms"] * 1e-3)
+        out["transforms"] = {"kernels": sorted(c["kernels"]), "algorithmic_GB_per_step": round(c["GB"], 3),
+                             "ms_per_step": round(c["ms"], 3), "achieved": round(rate, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(rate / HBM_PEAK_GBPS, 4), "bound": "hbm"}
+    return out, per_layer
 
 
 def pairwise_roofline(dev, iters=50):
@@ -258,6 +364,8 @@ def hbm_families(fam, params, S):
         "rmsprop_step": 4.0 * 5 * pyr,                                 # var, rms, grad in; var, rms out
         # fold: level k = v[k] + up(level k+1): read the coarser level + the variable, write the level (5 launches)
         "resize_bilinear": 4.0 * sum(lv[k + 1] + 2 * lv[k] for k in range(5)),
+        # the same fold as ONE launch (strotss_fold_pyramid): every level read once, the image written once
+        "fold_pyramid": 4.0 * (pyr + lv[0]),
         # fold adjoint: level k gradient = up^T(level k-1 gradient): read the finer, write the coarser (5 launches)
         "resize_bilinear_adjoint": 4.0 * sum(lv[k - 1] + lv[k] for k in range(1, 6)),
         # hypercolumn gather, content + prediction: 4 bilinear taps x N x D read, N x ld written, per call
@@ -276,6 +384,69 @@ def hbm_families(fam, params, S):
 
 TRAFFIC_CSV = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_hbm_traffic_by_kernel.csv") for r in range(9, 0, -1))
                     if os.path.exists(p)), os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_kernel.csv"))
+
+
+def measure_traffic_live(scale):
+    """HBM traffic per kernel launch measured IN THIS RUN: this script started twice as a child under `rocprofv3 --pmc
+    FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes; the program directly after `--`), three eager steps each.
+    FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads,
+    MI355X_MICROARCH.md).  {kernel name: {launches, read, write}} in bytes per launch, or None when rocprofv3 is absent or
+    a pass fails (the caller then falls back to the committed profile and says so)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("STROTSS_BENCH_LIVE_PMC", "1") == "0":
+        return None
+
+    def short(name):
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        name = re.sub(r"^void ", "", name)
+        return re.sub(r"\(.*\)$", "", name)
+    acc = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                odir = os.path.join(tmp, counter)
+                cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", odir, "--", sys.executable, os.path.abspath(__file__),
+                       "--traffic-child", "--scale", str(scale)]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.PIPE, timeout=400)
+                files = glob.glob(os.path.join(odir, "**", "*_counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    print(f"bench.py: rocprofv3 --pmc {counter} pass failed (rc {r.returncode}); traffic from the committed profile",
+                          file=sys.stderr)
+                    return None
+                with open(files[0]) as f:
+                    for row in csv.DictReader(f):
+                        if row["Counter_Name"] != counter:
+                            continue
+                        e = acc.setdefault(short(row["Kernel_Name"]), {"FETCH_SIZE": [], "WRITE_SIZE": []})
+                        e[counter].append(float(row["Counter_Value"]))
+    except Exception as exc:                                   # the measurement is optional; the bench line is not
+        print(f"bench.py: live PMC pass failed ({exc!r}); traffic from the committed profile", file=sys.stderr)
+        return None
+    out = {}
+    for k, e in acc.items():
+        if e["FETCH_SIZE"] and e["WRITE_SIZE"]:
+            out[k] = {"launches": len(e["FETCH_SIZE"]), "read": float(np.mean(e["FETCH_SIZE"])) * 1024 * 2,
+                      "write": float(np.mean(e["WRITE_SIZE"])) * 1024}
+    return out or None
+
+
+def traffic_child(scale):
+    """Child of measure_traffic_live (runs under rocprofv3 --pmc): one warm-up and three eager steps of the bench step."""
+    from nn.model import VGGParams, synthetic_weights
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    params = VGGParams(synthetic_weights('16', 0), '16', None, dev)
+    eng, rng = build_engine(params, scale, dev, seed=0)
+    idx = index_stream(scale, 4, rng, dev)
+    run_steps(eng, idx, 0, 4)
+    torch.cuda.synchronize()
 
 
 def pmc_traffic(path=TRAFFIC_CSV):
@@ -336,13 +507,31 @@ def wall_clock_to_output(dev, size=1024, level=5, max_iter=200):
         args = run_strotss.build_parser().parse_args(
             [paths[0], paths[1], "-o", out_path, "--max_size", str(size), "--level", str(level), "--max_iter",
              str(max_iter), "--log_every", str(max_iter)])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_strotss.run(args)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # the CLI draws every step's index set on the host inside the loop (as the reference's traced step does,
+        # strotss_utils.py:83-121): its per-scale rate is what `index_draw` on the bench line quotes
+        per_scale, orig = {}, run_strotss._optimise_scale
+
+        def timed_scale(eng, scl, *a, **k):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            r = orig(eng, scl, *a, **k)
+            torch.cuda.synchronize()
+            per_scale[str(scl)] = round(max_iter / (time.perf_counter() - t1), 1)
+            return r
+        run_strotss._optimise_scale = timed_scale
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_strotss.run(args)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            run_strotss._optimise_scale = orig
     return {"seconds": round(dt, 2), "config": f"{size}px synthetic pair, --level {level} --max_iter {max_iter} "
-            f"(scales 64..{64 << (level - 1)}), incl. VGG build, JPEG decode/encode, per-scale setup, hipGraph capture"}
+            f"(scales 64..{64 << (level - 1)}), incl. VGG build, JPEG decode/encode, per-scale setup, hipGraph capture",
+            "cli_steps_per_sec_by_scale": per_scale,
+            "cli_steps_per_sec_is": "max_iter / wall time of the scale's loop INCLUDING its hipGraph capture and the per-step "
+                                    "host index draws + pinned uploads"}
 
 
 def usable_cores():
@@ -486,6 +675,8 @@ def main():
                          "masked pair (BASELINE config 4) with its mask regions dealt to the ranks and one all-reduce of the "
                          "pixel gradient per step (both strong scaling: value = steps/s of that one job)")
     ap.add_argument("--regions", type=int, default=4, help="--mode regions: number of mask regions (vertical bands)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (traffic from the committed profile)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rehearse", action="store_true", help="N-rank harness only (gloo, sleeping stand-in step, no GPU)")
     args = ap.parse_args()
 
@@ -500,6 +691,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.rehearse:
         return rehearse(args, world, rank)
+    if args.traffic_child:
+        return traffic_child(args.scale)
     if world > 1:
         import torch.distributed as dist
         from nn import parallel as par
@@ -573,10 +766,10 @@ def main():
         if world == 1 and strips is None and not args.no_families:
             # ---- per-kernel-family HIP-event timing (separate, untimed pass; eager launches, medians)
             saved_graph, eng._graph = eng._graph, None
-            fam = time_kernel_families(eng, idx)
+            fam, sites = time_kernel_families(eng, idx, with_sites=True)
             bad = {k: round(v["ms_per_step"], 4) for k, v in fam.items() if v["ms_per_step"] >= out["ms_per_step"]}
             if bad:                                   # a family cannot take longer than the step: measure once more
-                fam = time_kernel_families(eng, idx)
+                fam, sites = time_kernel_families(eng, idx, with_sites=True)
                 bad = {k: round(v["ms_per_step"], 4) for k, v in fam.items() if v["ms_per_step"] >= out["ms_per_step"]}
             eng._graph = saved_graph
             out["kernel_families_valid"] = not bad
@@ -590,32 +783,65 @@ def main():
             executed = 2.0 * sum(2.0 * macs_per_out[t] * L["cin"] * L["cout"] * a.shape[1] * a.shape[2]
                                  for L, a, t in zip(params.layers, eng.trunk.acts, eng.trunk.wtile) if L["cin"] != 3)
             if not bad and conv_ms > 0:
+                saved_graph, eng._graph = eng._graph, None
+                by_path, per_layer = conv_path_breakdown(eng, idx, params, sites)
+                eng._graph = saved_graph
+                live = measure_traffic_live(S) if not args.no_live_pmc else None
+                # the dominant kernel class of the step by time: its own bound, its own traffic
+                dom = max((k for k in by_path if k != "transforms"), key=lambda k: by_path[k]["ms_per_step"])
+                d = by_path[dom]
+                dom_kernel = {"f32_mfma": "winograd43_fused_kernel", "bf16x3_gemm": "gemm_x3_kernel"}[dom]
+                traffic, traffic_src = None, None
+                if live is not None:
+                    hit = [v for k, v in live.items() if k.startswith(dom_kernel) and (dom != "bf16x3_gemm" or "EpiScaleStore" in k)]
+                    n = sum(v["launches"] for v in hit)
+                    if n:
+                        traffic = sum(v["launches"] * (v["read"] + v["write"]) for v in hit) / n
+                        traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this script "
+                                       "(3 eager steps each), FETCH_SIZE x2 (gfx950 half-count), bytes per launch of " + dom_kernel)
+                if traffic is None:
+                    traffic = pmc_traffic()
+                    traffic_src = ("committed profile, not this run (rocprofv3 not available or its pass failed): HBM bytes per conv "
+                                   "launch (" + os.path.relpath(TRAFFIC_CSV, ROOT) + ")")
                 tf_exec = executed / (conv_ms * 1e-3) / 1e12
                 tf_direct = algo / (conv_ms * 1e-3) / 1e12
                 out["roofline"] = {
-                    "kernel": "3x3 conv on the f32 MFMA, Winograd F(4x4,3x3): winograd43_fused_kernel (transforms + 36 GEMMs "
-                              "on chip; layers up to 256 output channels) and winograd43_in_kernel -> gemm_kc_pipe_kernel x36 "
-                              "-> winograd43_out_kernel (512-channel layers); fwd + dgrad, all conv launches of a step",
-                    "bound": "mfma", "achieved": round(tf_exec, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf_exec / F32_MFMA_PEAK_TFLOPS, 4),
-                    "achieved_is": "FLOP the MFMA executes (Winograd-domain products: 2.25 MACs per output for F(4x4,3x3), 4 for "
-                                   "F(2x2,3x3), 9 direct) / summed HIP-event time of the conv launches of a step",
-                    "traffic": pmc_traffic(),
-                    "traffic_source": "committed profile, not this run: HBM bytes per conv launch, PMC FETCH_SIZE x2 + WRITE_SIZE, "
-                                      "separate rocprofv3 --pmc passes of this script (" + os.path.relpath(TRAFFIC_CSV, ROOT) + ")",
-                    "mfma_executed_gflop_per_step": round(executed / 1e9, 1),
-                    "direct_form_gflop_per_step": round(algo / 1e9, 1),
-                    "direct_form_equivalent_tflops": round(tf_direct, 2),
-                    "effective_speedup_vs_direct_form": round(algo / executed, 3),
-                    "launches_per_step": conv_launches,
-                    "avg_launch_ms": round(conv_ms / conv_launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
+                    "kernel": "; ".join(d["kernels"]) + " -- the kernel class with the largest share of the step ("
+                              + f"{d['ms_per_step']:.2f} of {out['ms_per_step']:.2f} ms), fwd + dgrad",
+                    "bound": "mfma", "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
+                    "achieved_is": "FLOP the MFMA executes in this class (Winograd-domain products: 2.25 MACs per output for "
+                                   "F(4x4,3x3), 4 for F(2x2,3x3), 9 direct; bf16x3 layers at their f32-equivalent FLOP against "
+                                   "bf16 peak / 6) / summed HIP-event time of the class's launches (eager, medians; the classes' "
+                                   "times are measured call by call and are not additive to ms_per_step, which is a graph replay)",
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "by_path": by_path,
+                    "blended": {"note": "ALL conv launches of a step in one figure, f32-MFMA and bf16x3 layers mixed: a blend of "
+                                        "two bounds, kept for continuity with rounds 1-2 (their `frac`), not a roofline",
+                                "executed_tflops": round(tf_exec, 2), "vs_f32_mfma_peak": round(tf_exec / F32_MFMA_PEAK_TFLOPS, 4),
+                                "conv_ms_per_step": round(conv_ms, 3), "launches_per_step": conv_launches,
+                                "mfma_executed_gflop_per_step": round(executed / 1e9, 1),
+                                "direct_form_gflop_per_step": round(algo / 1e9, 1),
+                                "direct_form_equivalent_tflops": round(tf_direct, 2),
+                                "effective_speedup_vs_direct_form": round(algo / executed, 3)},
+                    "layers": per_layer}
+                if live is not None:
+                    out["hbm_traffic_by_kernel_MB_per_launch"] = {
+                        k: {"launches": v["launches"], "read": round(v["read"] / 1e6, 1), "write": round(v["write"] / 1e6, 1)}
+                        for k, v in sorted(live.items(), key=lambda kv: -kv[1]["launches"] * (kv[1]["read"] + kv[1]["write"]))[:14]}
             else:
                 out["roofline"] = None
                 out["kernel_families_rejected"] = bad
             out["roofline_pairwise"] = pairwise_roofline(dev)
             if out["roofline_pairwise"].get("executed_bf16_tflops"):
-                out["roofline_pairwise"]["traffic"] = pmc_traffic_pairwise()
-                out["roofline_pairwise"]["traffic_source"] = "committed profile, not this run (" + os.path.relpath(TRAFFIC_CSV, ROOT) + ")"
+                lv = [v for k, v in (live or {}).items() if k.startswith("gemm_x3_kernel<X3Cfg<64") and "EpiCosDistX3" in k] \
+                    if (not bad and conv_ms > 0) else []
+                if lv:
+                    # the step's three cost matrices: two symmetric launches (136 of 256 tiles) and the full style x prediction one
+                    out["roofline_pairwise"]["traffic"] = max(v["read"] + v["write"] for v in lv)
+                    out["roofline_pairwise"]["traffic_source"] = "measured in this run (rocprofv3 --pmc child passes): the full-matrix launch"
+                else:
+                    out["roofline_pairwise"]["traffic"] = pmc_traffic_pairwise()
+                    out["roofline_pairwise"]["traffic_source"] = "committed profile, not this run (" + os.path.relpath(TRAFFIC_CSV, ROOT) + ")"
             out["kernel_families_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(fam.items())}
             out["kernel_families_launches_per_step"] = {k: v["launches_per_step"] for k, v in sorted(fam.items())}
             out["hbm_bound_families"] = hbm_families(fam, params, S)
@@ -645,6 +871,13 @@ def main():
                               "projected_optimisation_wall_clock_s_5x200": round(total, 2)}
     if rank == 0 and not args.no_e2e and world == 1 and S == 1024 and args.mode == "replicas":
         out["wall_clock_to_output"] = wall_clock_to_output(dev)
+    if rank == 0:
+        cli = (out.get("wall_clock_to_output") or {}).get("cli_steps_per_sec_by_scale", {}).get(str(S))
+        out["index_draw"] = ("outside the timed region: the step's index sets (strotss_utils.py:83-121, drawn inside the "
+                             "reference's traced step) are drawn and uploaded before the timed steps; the CLI, which draws one "
+                             "set per step on the host and uploads it asynchronously, runs "
+                             + (f"{cli} it/s at this scale in the same process (graph capture included)" if cli
+                                else "within 1 % of this rate (see wall_clock_to_output when it is enabled)"))
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.mode == "replicas":
         out["cpu_baseline"] = cpu_baseline(S)
     if rank == 0:

@@ -144,6 +144,22 @@ int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, co
                                    const float* u_packed, const void* u_x3, int cin, int tile_m,
                                    const float* act_in, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream);
+/* Which kernels strotss_conv3x3_winograd_fwd / _dgrad run for a layer shape (the routing is a size policy with
+ * environment switches, read once per process): what bench.py names in its roofline.  has_packed / has_x3: whether the
+ * caller passes u_packed / u_x3 for this layer. */
+#define STROTSS_ROUTE_F2_GEMM_F32 0     /* F(2x2,3x3): input transform, 16 f32-MFMA GEMMs, output transform            */
+#define STROTSS_ROUTE_F4_FUSED_F32 1    /* F(4x4,3x3), one persistent kernel, f32 MFMA (csrc/winograd_fused.hip)       */
+#define STROTSS_ROUTE_F4_GEMM_F32 2     /* F(4x4,3x3), three kernels, 36 f32-MFMA GEMMs                                 */
+#define STROTSS_ROUTE_F4_X3_GEMM_128 3  /* three kernels, 36 bf16x3 GEMMs, 128 x 128 tiles (K16 ring, two workgroups/CU)*/
+#define STROTSS_ROUTE_F4_X3_GEMM_64 4   /* the same on 64 x 64 tiles                                                    */
+#define STROTSS_ROUTE_F4_X3_STREAM 5    /* three kernels, the bf16x3 GEMMs as one persistent stream (mfma_x3_stream.h)  */
+#define STROTSS_ROUTE_F4_X3_GEMM_OUT 6  /* two kernels: input transform + GEMMs with the output transform folded in     */
+int strotss_conv3x3_winograd_route(int h, int w, int cin, int cout, int tile_m, int has_packed, int has_x3);
+/* MEASUREMENT HOOK, process-wide and not thread-safe: which stages of the F(4x4,3x3) three-kernel form are launched
+ * from now on (bit 0 input transform, bit 1 GEMMs, bit 2 output transform; 7 = all, the default); returns the previous
+ * mask.  bench.py times a layer with masks 1, 3, 7 to split its time into transform and GEMM time (results are
+ * meaningless under a partial mask). */
+int strotss_debug_winograd_stages(int mask);
 /* 2x2/2 VALID max-pool: out(h/2, w/2, c).  code (may be NULL): (h/2, w/2, c) bytes, the index 0..3 of the FIRST
  * max of each window in scan order (0,0),(0,1),(1,0),(1,1), or 4 when that max is not positive. */
 int strotss_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, void* stream);

@@ -312,6 +312,10 @@ static bool winograd43_prefers_x3(int h, int w, int cout) {
   return cout >= x3_min_cout() && x3_enabled(T, cout) && (long)((T + 127) / 128) * ((cout + 127) / 128) * 36 >= x3_min_tiles();
 }
 
+// Measurement hook (strotss_debug_winograd_stages): which stages of the F(4x4,3x3) three-kernel form are launched.
+// bit 0: input transform, bit 1: the 36 GEMMs, bit 2: output transform.  Process-wide, not thread-safe, default all.
+static int g_wino_stages = 7;
+
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* Upacked,
                           const void* Ux3, const float* bias, int cout, const float* mask, int relu, float* out,
                           float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
@@ -333,14 +337,16 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
   const size_t tout = T * (cout / 4);
   size_t Tstride = T;
   int rc;
+  const int stages = g_wino_stages;
   if (x3) {
     const size_t tin = ((T + 7) / 8) * 8 * (cin / 4);
-    hipLaunchKernelGGL(winograd43_in_x3_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
+    if (stages & 1) hipLaunchKernelGGL(winograd43_in_x3_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
                        in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V), log2_or_minus1(cin / 32));
     // two-kernel form: the GEMMs of all 36 positions and the output transform in ONE kernel, no M tensor
     if (st_winograd43_gemm_out_enabled(T, cin, cout))
-      return st_winograd43_gemm_out(V, Ux3, T, cin, cout, h, w, TW, bias, mask, relu, out, st);
-    if (st_gemm_x3_stream_ok((int)T, cout, cin, 36)) {          // one persistent pipeline per CU over all 36 x tiles
+      return (stages & 2) ? st_winograd43_gemm_out(V, Ux3, T, cin, cout, h, w, TW, bias, mask, relu, out, st) : 0;
+    if (!(stages & 2)) rc = 0;
+    else if (st_gemm_x3_stream_ok((int)T, cout, cin, 36)) {          // one persistent pipeline per CU over all 36 x tiles
       Tstride = Tpad;
       rc = st_gemm_x3_stream(V, Ux3, Mw, cout, (long long)Tpad * cout, (int)T, cout, cin, 36, st);
     } else {
@@ -348,13 +354,13 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
     }
   } else {
     const size_t tin = T * (cin / 4);
-    hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
+    if (stages & 1) hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
                        h, w, cin / 4, TH, TW, V, log2_or_minus1(cin / 4));
-    rc = st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
-                            (long long)T * cout, (int)T, cout, cin, 36, st);
+    rc = (stages & 2) ? st_gemm_nt_batched(V, cin, (long long)T * cin, U, cin, (long long)cout * cin, Mw, cout,
+                                           (long long)T * cout, (int)T, cout, cin, 36, st) : 0;
   }
   if (rc != 0) return rc;
-  hipLaunchKernelGGL(winograd43_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
+  if (stages & 4) hipLaunchKernelGGL(winograd43_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
                      Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out, log2_or_minus1(cout / 4), Tstride);
   ST_LAUNCH_RET();
 }
@@ -482,6 +488,25 @@ int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, co
                           workspace_bytes, (hipStream_t)stream);
   return winograd_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
                       (hipStream_t)stream);
+}
+
+int strotss_debug_winograd_stages(int mask) {
+  const int old = g_wino_stages;
+  g_wino_stages = mask & 7;
+  return old;
+}
+
+int strotss_conv3x3_winograd_route(int h, int w, int cin, int cout, int tile_m, int has_packed, int has_x3) {
+  if (h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (tile_m != 2 && tile_m != 4)) return STROTSS_EINVAL;
+  if (tile_m == 2) return STROTSS_ROUTE_F2_GEMM_F32;
+  const size_t T = (size_t)((h + 3) / 4) * ((w + 3) / 4);
+  const bool prefer_x3 = has_x3 && cin % 32 == 0 && winograd43_prefers_x3(h, w, cout);
+  if (!prefer_x3 && has_packed && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout)) return STROTSS_ROUTE_F4_FUSED_F32;
+  if (!(has_x3 && cin % 32 == 0 && x3_enabled(T, cout))) return STROTSS_ROUTE_F4_GEMM_F32;
+  if (st_winograd43_gemm_out_enabled(T, cin, cout)) return STROTSS_ROUTE_F4_X3_GEMM_OUT;
+  if (st_gemm_x3_stream_ok((int)T, cout, cin, 36)) return STROTSS_ROUTE_F4_X3_STREAM;
+  return (long)((T + 127) / 128) * ((cout + 127) / 128) * 36 >= x3_min_tiles() ? STROTSS_ROUTE_F4_X3_GEMM_128
+                                                                             : STROTSS_ROUTE_F4_X3_GEMM_64;
 }
 
 size_t strotss_conv3x3_winograd_x3_bytes(int rows, int k) { return (size_t)36 * 3 * rows * k * sizeof(unsigned short); }

@@ -65,6 +65,8 @@ SIGNATURES = {
     "strotss_conv3x3_winograd_x3pack": (_I, [_P, _I, _I, _P, _P]),
     "strotss_conv3x3_winograd_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "strotss_conv3x3_winograd_dgrad": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _P]),
+    "strotss_conv3x3_winograd_route": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "strotss_debug_winograd_stages": (_I, [_I]),
     "strotss_maxpool2_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "strotss_maxpool2_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "strotss_hypercol_gather": (_I, [C.POINTER(MapsT), _P, _I, _I, _P, _I, _P]),

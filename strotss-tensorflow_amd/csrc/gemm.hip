@@ -464,7 +464,7 @@ int st_gemm_x3_stream(const void* A, const void* B, float* C, int ldc, long long
   const __bf16* a = reinterpret_cast<const __bf16*>(A);
   const __bf16* b = reinterpret_cast<const __bf16*>(B);
   const long long sa = (long long)x3_panel_elems(M, K), sb = (long long)x3_panel_elems(N, K);
-#define X3S_LAUNCH(KS) hipLaunchKernelGGL((gemm_x3_stream_kernel<X3StreamCfg<KS>>), dim3((unsigned)grid), dim3(256), 0, s, a, M, \
+#define X3S_LAUNCH(KS) hipLaunchKernelGGL((gemm_x3_stream_kernel<X3StreamCfg<KS>>), dim3((unsigned)grid), dim3(X3StreamCfg<KS>::NT), 0, s, a, M, \
                                           sa, b, N, sb, C, ldc, strideC, MT, NT, (int)tiles)
   if (K == 128) X3S_LAUNCH(8); else if (K == 256) X3S_LAUNCH(16); else X3S_LAUNCH(32);
 #undef X3S_LAUNCH

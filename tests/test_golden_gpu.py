@@ -73,7 +73,7 @@ def test_trace_against_fixture():
     for k in range(6):
         ref = z[f"grad0_level{k}"]
         rel = np.linalg.norm(eng.gvars[k].cpu().numpy() - ref) / np.linalg.norm(ref)
-        assert rel < 2e-2, (k, rel)
+        assert rel < 5e-3, (k, rel)          # see GRAD_TOL in test_hip_engine.py
     eng.apply_gradients()
     for it in range(1, idx.shape[0]):
         eng.step([idx[it]])

@@ -13,6 +13,12 @@ from oracle import strotss_oracle as O
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
+# One step's six variable gradients against the float64 oracle, relative L2.  What the linear backward chain itself
+# contributes is measured by test_engine_backward_chain_without_sign_flips (<= 3e-4: Winograd F(4x4,3x3) rounding through 13
+# layers); the losses add the rounding of their own gradients (L1 / hard-min terms: an entry of sign(a - b) or an arg-min
+# flips where |a - b| is below float32 rounding, which changes one sample's row of dL/d(features), a 1e-3-relative event at
+# 256-1024 samples).  Round 2 allowed 2e-2 everywhere; measured over all step tests of this file: 3.1e-3 at most.
+GRAD_TOL = 5e-3
 
 
 def _img(h, w, seed):
@@ -73,7 +79,7 @@ def _check_step(S, masked):
     assert (eng.fold[0].cpu().double() - ref["img"]).abs().max() < 5e-6
     for k, (g, gr) in enumerate(zip(eng.gvars, ref["grads"])):
         rel = float((g.cpu().double() - gr).norm() / gr.norm())
-        assert rel < 2e-2, (k, rel)          # L1/hard-min losses: isolated sign flips vs f64 (see test_hip_ops)
+        assert rel < GRAD_TOL, (k, rel)
     # one RMSprop update applied to the same gradients must agree tightly
     gsnap = [g.clone() for g in eng.gvars]
     eng.apply_gradients()
@@ -120,7 +126,7 @@ def test_engine_multi_step_resynchronised():
             assert abs(got[k] - float(ref[k])) < 5e-5 * max(1.0, abs(float(ref[k]))), (it, k, got[k], float(ref[k]))
         for k, (g, gr) in enumerate(zip(eng.gvars, ref["grads"])):
             rel = float((g.cpu().double() - gr).norm() / gr.norm())
-            assert rel < 2e-2, (it, k, rel)
+            assert rel < GRAD_TOL, (it, k, rel)
         gsnap = [g.cpu().double() for g in eng.gvars]
         eng.apply_gradients()
         with torch.no_grad():
@@ -555,3 +561,41 @@ def test_step_parity_with_the_fused_winograd_kernel_forced():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+def test_full_scale_winograd_vs_direct(tmp_path):
+    """SURVEY.md 7's end-to-end criterion for the Winograd forms: a WHOLE scale of the schedule (128 px, 200 steps, the CLI's
+    own loop and index stream) in child processes -- default convolution routing (F(4x4,3x3) / F(2x2,3x3) / split-K direct,
+    whatever the size policy picks) against STROTSS_WINOGRAD=0 (the direct f32-MFMA form everywhere, 16x less rounding
+    error).  The optimisation is chaotic at rounding level (RMSprop's first updates are sign-like, the losses are L1 /
+    hard-min terms), so the yardstick is a CONTROL: the direct form once more with the learning rate changed by 1e-7
+    relative.  The Winograd run must stay as close to the direct run as the control does (loss curves: median deviation
+    within 3x the control's, never above 5 %; converged loss level within 3 %; output PSNR within 3 dB of the control's)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from nn import utils
+    for name, seed in (("c.jpg", 11), ("s.jpg", 12)):
+        utils.write_image(_img(128, 128, seed) * 255.0, str(tmp_path / name))
+    outs = {}
+    for tag, env, lr in (("wino", {}, "2e-3"), ("direct", {"STROTSS_WINOGRAD": "0"}, "2e-3"),
+                         ("control", {"STROTSS_WINOGRAD": "0"}, "2.0000002e-3")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_scale_worker.py"), str(tmp_path / tag),
+                            str(tmp_path / "c.jpg"), str(tmp_path / "s.jpg"), lr], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag] = np.load(str(tmp_path / tag) + ".npz")
+    lw, ld, lc = (outs[k]["losses"][:, 0] for k in ("wino", "direct", "control"))
+    assert lw.shape == ld.shape == lc.shape == (200,)
+    dev_w, dev_c = np.abs(lw - ld) / np.abs(ld), np.abs(lc - ld) / np.abs(ld)
+    assert dev_w[0] < 1e-4, dev_w[0]                              # the same first step to rounding
+
+    def psnr(a, b):
+        return 10 * np.log10(1.0 / np.mean((np.clip(a.astype(np.float64), 0, 1) - np.clip(b.astype(np.float64), 0, 1)) ** 2))
+    p_w, p_c = psnr(outs["wino"]["final"], outs["direct"]["final"]), psnr(outs["control"]["final"], outs["direct"]["final"])
+    print(f"128 px, 200 steps, against the direct form: Winograd routing median loss deviation {np.median(dev_w):.2e} (worst "
+          f"{dev_w.max():.2e}), PSNR {p_w:.1f} dB; control (lr x (1 + 1e-7)) {np.median(dev_c):.2e} (worst {dev_c.max():.2e}), "
+          f"PSNR {p_c:.1f} dB; loss {ld[0]:.3f} -> {ld[-20:].mean():.3f} / {lw[-20:].mean():.3f}")
+    assert np.median(dev_w) <= max(3 * np.median(dev_c), 1e-2) and np.median(dev_w) < 5e-2, (np.median(dev_w), np.median(dev_c))
+    assert abs(lw[-20:].mean() - ld[-20:].mean()) < 3e-2 * ld[-20:].mean()
+    assert ld[-20:].mean() < 0.8 * ld[0] and lw[-20:].mean() < 0.8 * lw[0]      # and it IS an optimisation
+    assert p_w >= p_c - 3.0, (p_w, p_c)

@@ -144,7 +144,7 @@ def test_strip_sharded_step_matches_the_float64_oracle():
         assert abs(got[k] - float(ref[k])) < 5e-5 * max(1.0, abs(float(ref[k]))), (k, got[k], float(ref[k]))
     for k, (a, b) in enumerate(zip(engs[0].gvars, ref["grads"])):
         rel = float((a.cpu().double() - b).norm() / b.norm())
-        assert rel < 2e-2, (k, rel)
+        assert rel < 5e-3, (k, rel)          # see GRAD_TOL in test_hip_engine.py
 
 
 def test_strip_margin_must_cover_the_receptive_field():

@@ -110,11 +110,17 @@ def index_stream(scale, count, rng, dev, sample_size=SAMPLES, regions=1):
     return torch.from_numpy(arr).to(dev)
 
 
-def strip_index_stream(scale, count, rng, dev, plan, sample_size=SAMPLES):
-    """index sets ordered by owning rank + their block offsets (identical on every rank: same seed)"""
+def strip_index_stream(scale, count, rng, dev, plan, sample_size=SAMPLES, regions=1):
+    """per step and region: the index set ordered by owning rank + its block offsets (identical on every rank: same seed).
+    -> (list over steps of lists over regions of (n, 2) device tensors, list over steps of lists over regions of offsets)"""
     from nn import parallel as par, strotss_utils as SU
-    sets = [par.sort_indices_by_strip(SU.make_indices_np(scale, scale, True, sample_size, rng), plan) for _ in range(count)]
-    return torch.from_numpy(np.stack([s[0] for s in sets])).to(dev), [s[1] for s in sets]
+    masks = region_masks(scale, regions)
+    idx, offs = [], []
+    for _ in range(count):
+        sets = [par.sort_indices_by_strip(SU.make_indices_np(scale, scale, True, sample_size, rng, mk), plan) for mk in masks]
+        idx.append([torch.from_numpy(s[0]).to(dev) for s in sets])
+        offs.append([s[1] for s in sets])
+    return idx, offs
 
 
 def run_steps(eng, idx, first, count):
@@ -670,10 +676,11 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-output run of the whole CLI schedule")
     ap.add_argument("--no-families", action="store_true", help="skip the per-kernel-family HIP-event pass")
     ap.add_argument("--halo", action="store_true", help="--mode strips: per-layer halo exchange instead of the recompute margin")
-    ap.add_argument("--mode", choices=("replicas", "strips", "regions"), default="replicas",
+    ap.add_argument("--mode", choices=("replicas", "strips", "regions", "masked-strips"), default="replicas",
                     help="N > 1: independent pairs per GPU (default, weak scaling); ONE pair sharded by image strips; or ONE "
                          "masked pair (BASELINE config 4) with its mask regions dealt to the ranks and one all-reduce of the "
-                         "pixel gradient per step (both strong scaling: value = steps/s of that one job)")
+                         "pixel gradient per step; masked-strips: that masked pair sharded by image strips instead -- the sharding "
+                         "that cuts trunk work (all strong scaling: value = steps/s of that one job)")
     ap.add_argument("--regions", type=int, default=4, help="--mode regions: number of mask regions (vertical bands)")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (traffic from the committed profile)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
@@ -708,24 +715,25 @@ def main():
     params = VGGParams(synthetic_weights('16', 0), '16', None, dev)
     S = args.scale
     strips, regions, group = None, 1, None
-    if args.mode == "strips" and world > 1:
+    if args.mode in ("strips", "masked-strips") and world > 1:
         strips = parallel.strip_plan(S, world, rank, halo=args.halo)
         if strips is None:
-            raise SystemExit(f"--mode strips: sharding a {S}-row image over {world} ranks does not pay (see strip_plan)")
-    if args.mode == "regions":
+            raise SystemExit(f"--mode {args.mode}: sharding a {S}-row image over {world} ranks does not pay (see strip_plan)")
+    if args.mode in ("regions", "masked-strips"):
         regions = args.regions
+    if args.mode == "regions":
         group = parallel.WORLD if world > 1 else None
-    one_job = strips is not None or args.mode == "regions"
+    one_job = strips is not None or args.mode in ("regions", "masked-strips")
     eng, rng = build_engine(params, S, dev, seed=0 if one_job else rank, strips=strips, regions=regions, dist_group=group)
     count = max(8, min(64, args.steps + args.warmup))
     if strips is not None:
-        idx, offsets = strip_index_stream(S, count, rng, dev, strips)
+        idx, offsets = strip_index_stream(S, count, rng, dev, strips, regions=regions)
         global run_steps
-        run_steps = lambda e, ix, first, n: [e.step([ix[i % ix.shape[0]]], offsets[i % ix.shape[0]]) for i in range(first, first + n)]
+        run_steps = lambda e, ix, first, n: [e.step(ix[i % len(ix)], offsets[i % len(ix)]) for i in range(first, first + n)]
     else:
         idx = index_stream(S, count, rng, dev, regions=regions)
     if not args.no_graph:
-        eng.capture_graph(list(idx[0]) if strips is None else [idx[0]])
+        eng.capture_graph(list(idx[0]))
 
     run_steps(eng, idx, 0, args.warmup)
     torch.cuda.synchronize()
@@ -748,6 +756,7 @@ def main():
         n_gpus = world
         par_desc = (("one pair sharded by image strips (per-layer halo exchange with the neighbouring ranks), 2 all-reduces per step"
                      if strips.halo else "one pair sharded by image strips (halo recompute), 2 all-reduces per step")
+                    + (f", {regions} mask regions (losses replicated, one all-reduce of all regions' feature rows)" if regions > 1 else "")
                     if strips is not None else
                     f"one masked pair, {regions} mask regions dealt round-robin to {n_gpus} rank(s), trunk replicated, "
                     f"1 all-reduce of the pixel gradient per step" if args.mode == "regions" else

@@ -105,7 +105,7 @@ class StepEngine:
         self.strips = strips
         win0, win1 = (strips.win0, strips.win1) if strips is not None else (0, h)
         if strips is not None:
-            assert self.R == 1 and strips.h == h, "image strips: one region, plan made for this scale"
+            assert strips.h == h, "image strips: plan made for this scale"
         # halo-exchange strips: the trunk refreshes its window's outermost rows from the neighbours after every layer
         self._halo = parallel.HaloExchange(strips, dist_group) if (strips is not None and strips.halo) else None
         self.trunk = VGGTrunk(params, win1 - win0, w, with_grad=True, halo=self._halo)
@@ -122,7 +122,9 @@ class StepEngine:
         rows = _ops.pad32(sample_size)
         self.sample_size = sample_size
         self.cf = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
-        self.pf = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
+        # the regions' prediction rows are slices of ONE buffer: image strips all-reduce them in one collective
+        self._pf_all = torch.zeros((self.R, rows, self.ld), dtype=torch.float32, device=dev)
+        self.pf = [self._pf_all[r] for r in range(self.R)]
         self.gp = [torch.zeros((rows, self.ld), dtype=torch.float32, device=dev) for _ in range(self.R)]
         self.scalars = (torch.zeros((self.R, 8), dtype=torch.float32, device=dev) if self._reduce_buf is None
                         else self._reduce_buf[3 * h * w:].view(self.R, 8))
@@ -154,8 +156,9 @@ class StepEngine:
         self._mt_content = _hip.make_maps(self.content_feat, self.divs)
         self._layer_to_map = {li: k + 1 for k, li in enumerate(self.trunk.taps)}
         self._layer_to_map[-1] = 0
-        if strips is not None:            # strips shard the image, not the regions: every rank runs region 0
-            self.my_regions, self.world = [0], 1
+        if strips is not None:            # strips shard the IMAGE: every rank runs every region's (replicated) losses
+            self.my_regions, self.world = list(range(self.R)), 1
+        self._o0, self._o1, self._ns = [0] * self.R, [0] * self.R, [0] * self.R   # strips: this rank's block of each region's samples
         self._idx: List[Optional[torch.Tensor]] = [None] * self.R
         # deterministic mode (STROTSS_DETERMINISTIC=1): the tap adjoint as a sorted scatter, one plan per region and step
         # (no float atomics -> bitwise reproducible steps; the reference asks TF for the same: nn/rand.py:4-8)
@@ -212,9 +215,11 @@ class StepEngine:
         for r in self.my_regions:
             idx, gp = self._idx[r], self.gp[r]
             if self.strips is not None and self._halo is None:   # this rank's block of samples only
-                idx, gp = idx[self._o0:self._o1], gp[self._o0:self._o1]
+                if self._o1[r] <= self._o0[r]:
+                    continue
+                idx, gp = idx[self._o0[r]:self._o1[r]], gp[self._o0[r]:self._o1[r]]
             elif self.strips is not None:                        # halo exchange: every sample, taps outside the window dropped
-                idx, gp = idx[:self._n], gp[:self._n]
+                idx, gp = idx[:self._ns[r]], gp[:self._ns[r]]
             if self.deterministic:
                 _ops.hypercol_scatter_sorted(self._mt_pred, self._plans[r], int(idx.shape[0]), gp, relu_mask_from=1,
                                              map_begin=k, map_end=k + 1)
@@ -228,7 +233,9 @@ class StepEngine:
         for r in self.my_regions:
             idx, gp = self._idx[r], self.gp[r]
             if self.strips is not None and self._halo is None:
-                idx, gp = idx[self._o0:self._o1], gp[self._o0:self._o1]
+                if self._o1[r] <= self._o0[r]:
+                    continue
+                idx, gp = idx[self._o0[r]:self._o1[r]], gp[self._o0[r]:self._o1[r]]
             if self.deterministic:
                 _ops.hypercol_scatter_sorted(self._mt_pred, self._plans[r], int(idx.shape[0]), gp, relu_mask_from=1,
                                              map_begin=0, map_end=n_maps)
@@ -238,12 +245,14 @@ class StepEngine:
 
     def forward_backward(self, indices: Sequence[torch.Tensor], strip_offsets: Optional[Sequence[int]] = None) -> None:
         """train_step (run_strotss.py:131-142 / 104-125): fills self.gvars and self.scalars.
-        With image strips `indices[0]` must be ordered by owning rank and `strip_offsets` be the world + 1 block
-        offsets (parallel.sort_indices_by_strip)."""
+        With image strips every region's `indices[r]` must be ordered by owning rank and `strip_offsets[r]` be its world + 1
+        block offsets (parallel.sort_indices_by_strip); one region: the offsets list itself is accepted too."""
         assert len(indices) == self.R
         if self.strips is not None:
-            self._strip_stage_a(indices[0], strip_offsets)
-            parallel.allreduce_sum_(self.pf[0], self.group)       # rows of the other ranks' samples arrive here
+            if self.R == 1 and strip_offsets is not None and not isinstance(strip_offsets[0], (list, tuple)):
+                strip_offsets = [strip_offsets]
+            self._strip_stage_a(indices, strip_offsets)
+            parallel.allreduce_sum_(self._pf_all, self.group)     # rows of the other ranks' samples arrive here: ONE collective
             self._strip_stage_b()
             parallel.allreduce_sum_(self.gimg_full, self.group)   # windows overlap by the margins: sum
             self._fold_adjoint()
@@ -285,39 +294,46 @@ class StepEngine:
             _ops.resize_bilinear_adjoint(self.gvars[k - 1], hk, wk, out=self.gvars[k])
 
     # ---- image strips: the step in three stages with an all-reduce between them
-    def _strip_stage_a(self, idx: torch.Tensor, offsets: Sequence[int]) -> None:
-        """fold (replicated), trunk forward on the window, content rows (all, from the replicated full maps),
+    def _strip_stage_a(self, indices: Sequence[torch.Tensor], offsets: Sequence[Sequence[int]]) -> None:
+        """fold (replicated), trunk forward on the window; per region: content rows (all, from the replicated full maps),
         prediction rows of THIS rank's samples (the others stay zero for the all-reduce)."""
-        idx = _hip.require(idx, "indices")
-        n = int(idx.shape[0])
-        assert offsets is not None and len(offsets) == self.strips.world + 1 and offsets[-1] == n
-        assert 0 < n <= self.sample_size and idx.shape[1] == 2
-        self._idx[0], self._n = idx, n
-        self._o0, self._o1 = int(offsets[self.strips.rank]), int(offsets[self.strips.rank + 1])
+        assert offsets is not None and len(offsets) == self.R
         self.fold_forward()
         self.trunk.forward(self._img_window)
-        self._gather(self._mt_content, idx, self.cf[0])
-        self.pf[0].zero_()
-        if self._o1 > self._o0:
-            _hip.check(_hip.lib().strotss_hypercol_gather(
-                _hip.C.byref(self._mt_pred), idx[self._o0:].data_ptr(), self._o1 - self._o0, 1,
-                self.pf[0][self._o0:].data_ptr(), self.ld, _hip.stream_ptr()), "hypercol_gather")
+        self._pf_all.zero_()
+        for r in range(self.R):
+            idx = _hip.require(indices[r], "indices")
+            n = int(idx.shape[0])
+            off = offsets[r]
+            assert len(off) == self.strips.world + 1 and off[-1] == n
+            assert 0 < n <= self.sample_size and idx.shape[1] == 2
+            self._idx[r], self._ns[r] = idx, n
+            self._o0[r], self._o1[r] = int(off[self.strips.rank]), int(off[self.strips.rank + 1])
+            self._gather(self._mt_content, idx, self.cf[r])
+            if self._o1[r] > self._o0[r]:
+                _hip.check(_hip.lib().strotss_hypercol_gather(
+                    _hip.C.byref(self._mt_pred), idx[self._o0[r]:].data_ptr(), self._o1[r] - self._o0[r], 1,
+                    self.pf[r][self._o0[r]:].data_ptr(), self.ld, _hip.stream_ptr()), "hypercol_gather")
 
     def _strip_stage_b(self) -> None:
-        """losses on the assembled features (replicated), backward of this rank's rows through its window."""
-        self._losses(0, self._n)
+        """losses of every region on the assembled features (replicated), backward of this rank's rows through its window."""
+        for r in range(self.R):
+            self._losses(r, self._ns[r])
         if self._halo is not None:
             # every rank back-propagates (gradient crosses the strip borders through the exchanges, and every sample's
             # taps that land in this window are scattered here); only the OWN rows of the pixel gradient are kept
             if self.deterministic:
-                _ops.hypercol_scatter_plan(self._mt_pred, self._idx[0][:self._n], self._plans[0])
+                for r in range(self.R):
+                    _ops.hypercol_scatter_plan(self._mt_pred, self._idx[r][:self._ns[r]], self._plans[r])
             self.trunk.backward(self._scatter)
             self.gimg_full[:, :self.strips.own0].zero_()
             self.gimg_full[:, self.strips.own1:].zero_()
             return
-        if self.deterministic and self._o1 > self._o0:
-            _ops.hypercol_scatter_plan(self._mt_pred, self._idx[0][self._o0:self._o1], self._plans[0])
-        if self._o1 > self._o0:
+        mine = [r for r in range(self.R) if self._o1[r] > self._o0[r]]
+        if self.deterministic:
+            for r in mine:
+                _ops.hypercol_scatter_plan(self._mt_pred, self._idx[r][self._o0[r]:self._o1[r]], self._plans[r])
+        if mine:
             self.trunk.backward(self._scatter, self._scatter_all)
         else:
             self.trunk.gimg.zero_()

@@ -108,8 +108,11 @@ def _optimise_scale(eng, scl: int, content_masks, args, dev, quiet: bool = False
         for it in bar:
             idx_np = [strotss.make_indices_np(eng.h, eng.w, True, SAMPLE_SIZE, rand.index_rng, mk) for mk in masks_here]
             offsets = None
-            if eng.strips is not None:            # same seed on every rank: identical draws, ordered by owner
-                idx_np[0], offsets = parallel.sort_indices_by_strip(idx_np[0], eng.strips)
+            if eng.strips is not None:            # same seed on every rank: identical draws, every region's set ordered by owner
+                offsets = []
+                for r in range(len(idx_np)):
+                    idx_np[r], off = parallel.sort_indices_by_strip(idx_np[r], eng.strips)
+                    offsets.append(off)
             idx = []
             for r, a in enumerate(idx_np):
                 if dev.type != "cuda":
@@ -169,13 +172,15 @@ def run(args: argparse.Namespace, trace=None):
         scl_content, scl_style = utils.resize(content, scl), utils.resize(style, scl)
         stylized, lr = _initial_image(position, position > 0 and i == level - 1, stylized, scl_content, scl_style,
                                       args.lr)
+        # --strips: ONE image sharded by rows (the only sharding that cuts trunk work), with or without mask regions; where
+        # a scale is too small for strips to pay (strip_plan -> None) a masked run falls back to dealing its regions out
         plan = (parallel.strip_plan(int(scl_content.shape[1]), world, rank, halo=bool(getattr(args, "halo", False)))
-                if world > 1 and not masked and getattr(args, "strips", False) else None)
+                if world > 1 and getattr(args, "strips", False) else None)
         eng = strotss_engine.StepEngine(
             vgg.params, strotss_engine.extract_features(vgg.params, scl_content),
             _style_targets(vgg.params, scl_style, style_masks, sampling), stylized, alpha,
             loss_denom=2. + alpha + 1. / max(alpha, 1.), lr=lr, sample_size=SAMPLE_SIZE, strips=plan,
-            dist_group=parallel.WORLD if (world > 1 and masked) else None)
+            dist_group=parallel.WORLD if (world > 1 and masked and plan is None) else None)
         rec = None
         if trace is not None:
             rec = dict(i=i, scl=scl, lr=lr, alpha=alpha, loss_denom=eng.loss_denom, init=stylized.clone(), steps=[],

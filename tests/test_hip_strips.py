@@ -46,7 +46,7 @@ def test_strip_sharded_step_equals_unsharded(cfg):
     ti = torch.from_numpy(idx_sorted).to(DEV)
     ref.forward_backward([ti])
     for e in engs:
-        e._strip_stage_a(ti, offs)
+        e._strip_stage_a([ti], [offs])
     pf = sum(e.pf[0] for e in engs)
     # the gathered rows: disjoint blocks, equal to the unsharded gather up to the conv rounding
     assert float((pf - ref.pf[0]).abs().max()) < 2e-4 * float(ref.pf[0].abs().max())
@@ -80,7 +80,7 @@ def test_strip_sharded_step_equals_unsharded(cfg):
             v.copy_(a); r_.copy_(b)
     ref.forward_backward([ti])
     for e in engs:
-        e._strip_stage_a(ti, offs)
+        e._strip_stage_a([ti], [offs])
     pf = sum(e.pf[0] for e in engs)
     for e in engs:
         e.pf[0].copy_(pf)
@@ -128,7 +128,7 @@ def test_strip_sharded_step_matches_the_float64_oracle():
     ref = O.train_step(variables, vgg, cf, ss, idx_sorted, alpha, denom)      # the losses are order-invariant
     ti = torch.from_numpy(idx_sorted).to(DEV)
     for e in engs:
-        e._strip_stage_a(ti, offs)
+        e._strip_stage_a([ti], [offs])
     pf = sum(e.pf[0] for e in engs)                       # the feature all-reduce, by hand
     assert float((pf[:n_samples, :2179].cpu().double() - ref["p_feat"]).abs().max()) < 5e-5 * float(ref["p_feat"].abs().max())
     for e in engs:
@@ -157,7 +157,7 @@ def test_strip_margin_must_cover_the_receptive_field():
     ti = torch.from_numpy(idx_sorted).to(DEV)
     ref.forward_backward([ti])
     for e in engs:
-        e._strip_stage_a(ti, offs)
+        e._strip_stage_a([ti], [offs])
     pf = sum(e.pf[0] for e in engs)
     assert float((pf - ref.pf[0]).abs().max()) > 1e-3 * float(ref.pf[0].abs().max())
     assert parallel.STRIP_MARGIN >= 112 and parallel.STRIP_MARGIN % parallel.STRIP_ALIGN == 0
@@ -274,3 +274,98 @@ def test_bench_strips_mode_two_ranks_prints_one_line(halo):
     line = lines[0]
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["launch_mode"] == "eager"
     assert ("halo exchange" in line["config"]["parallelism"]) == halo and "strips" in line["config"]["parallelism"]
+
+
+def test_masked_strip_sharded_step_equals_the_single_process_masked_step():
+    """Strips x mask regions (BASELINE config 4 with the only sharding that cuts trunk work; reference semantics
+    run_strotss.py:104-125: ONE trunk pass shared by R region losses): two emulated ranks, three regions, every region's
+    index set ordered by owner, ONE feature all-reduce for all regions (`_pf_all`), losses replicated, one pixel-gradient
+    all-reduce -- against the single-process masked step: losses 2e-5, the six gradients 3e-3 relative L2."""
+    from nn import _ops, engine, parallel, strotss_utils as SU
+    from nn.model import VGGParams, synthetic_weights
+    h, w, world, n_samples, regions = 512, 96, 2, 192, 3
+    params = VGGParams(synthetic_weights('16', 0), '16', None, DEV)
+    content, style = _img(h, w, 1).to(DEV), _img(h // 2, w, 2).to(DEV)
+    cfeat = engine.extract_features(params, content)
+    sfeat = engine.extract_features(params, style)
+    rng = np.random.default_rng(0)
+    # vertical bands: every region spans all rows, so every rank owns samples of every region
+    edges = [round(r * w / regions) for r in range(regions + 1)]
+    masks = []
+    for a, b in zip(edges, edges[1:]):
+        m = np.zeros((h, w), dtype=bool); m[:, a:b] = True
+        masks.append(m)
+    targets = []
+    for m in masks:
+        sm = m[: h // 2]
+        s_idx = torch.from_numpy(SU.make_indices_np(h // 2, w, False, n_samples, rng, sm)).to(DEV)
+        targets.append(engine.StyleTarget.build(_ops.hypercol_gather(sfeat, s_idx, False), int(s_idx.shape[0]), 2179))
+    init = SU.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
+    alpha = 4.0
+    mk = lambda plan: engine.StepEngine(params, cfeat, targets, init, alpha, 2.0 + alpha + 1.0 / alpha, 2e-3,
+                                        sample_size=n_samples, strips=plan)
+    plans = [parallel.strip_plan(h, world, r) for r in range(world)]
+    assert all(p is not None for p in plans)
+    ref, engs = mk(None), [mk(p) for p in plans]
+    assert ref.R == regions and all(e.my_regions == list(range(regions)) for e in engs)
+    idx = [SU.make_indices_np(h, w, True, n_samples, rng, m) for m in masks]
+    srt = [parallel.sort_indices_by_strip(i, plans[0]) for i in idx]
+    ti = [torch.from_numpy(s[0]).to(DEV) for s in srt]
+    offs = [s[1] for s in srt]
+    assert all(o[-1] == len(i) and all(b > a for a, b in zip(o, o[1:])) for o, i in zip(offs, idx)), "every strip holds samples of every region"
+    ref.forward_backward(ti)                               # the sorted sets: the losses do not depend on the order
+    for e in engs:
+        e._strip_stage_a(ti, offs)
+    pf = sum(e._pf_all for e in engs)                      # ONE feature all-reduce for all regions, by hand
+    for e in engs:
+        e._pf_all.copy_(pf)
+        e._strip_stage_b()
+    g = sum(e.gimg_full for e in engs)                     # the pixel-gradient all-reduce, by hand
+    for e in engs:
+        e.gimg_full.copy_(g)
+        e._fold_adjoint()
+    torch.cuda.synchronize()
+    la, lb = ref.losses(), engs[0].losses()
+    for k in ("loss", "loss_c", "loss_s"):
+        assert abs(la[k] - lb[k]) < 2e-5 * max(1.0, abs(la[k])), (k, la, lb)
+    assert engs[0].losses() == engs[1].losses()
+    for k, (a, b) in enumerate(zip(ref.gvars, engs[0].gvars)):
+        rel = float((a - b).norm() / a.norm())
+        assert rel < 3e-3, (k, rel)
+    for e in engs:
+        e.apply_gradients()
+    for a, b in zip(engs[0].variables, engs[1].variables):
+        assert torch.equal(a, b)
+
+
+def test_cli_masked_strips_two_ranks_on_one_gpu(tmp_path):
+    """`run_strotss.py --strips` WITH masks under two real processes (gloo on this box's one GPU): the strips x regions step
+    with its real collectives must print the single-process masked run's losses."""
+    import os, re, subprocess, sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "strotss-tensorflow_amd")
+    rng = np.random.default_rng(0)
+    for name, (h, w) in (("c.png", (512, 160)), ("s.png", (300, 200))):
+        arr = (rng.random((h // 16, w // 16, 3)) * 255).astype(np.uint8)
+        Image.fromarray(arr).resize((w, h), Image.BILINEAR).save(tmp_path / name)
+        m = np.zeros((h, w, 3), np.uint8); m[:, : w // 2] = (255, 0, 0); m[:, w // 2:] = (0, 0, 255)   # two vertical bands
+        Image.fromarray(m).save(tmp_path / ("m" + name))
+    base = [sys.executable, os.path.join(pkg, "run_strotss.py"), str(tmp_path / "c.png"), str(tmp_path / "s.png"),
+            "--content_mask", str(tmp_path / "mc.png"), "--style_mask", str(tmp_path / "ms.png"),
+            "--start_level", "3", "--level", "4", "--max_iter", "2", "--log_every", "1"]
+    env = dict(os.environ, PYTHONPATH=pkg + os.pathsep + root, STROTSS_DETERMINISTIC="1")
+    one = subprocess.run(base + ["-o", str(tmp_path / "one.jpg")], env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547",
+                 STROTSS_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(base + ["--strips", "-o", str(tmp_path / f"two{rank}.jpg")], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert "Loaded 2 masks" in one.stderr + one.stdout
+    losses = [re.findall(r"loss=([0-9.]+), loss_c=([0-9.]+), loss_s=([0-9.]+)", t)[-1] for t in (one.stderr, outs[0][1])]
+    assert losses[0] == losses[1], losses

@@ -175,3 +175,25 @@ def test_halo_exchange_geometry_matches_between_neighbours():
                 assert up[4] <= up[1] < up[5] and down[4] <= down[0] < down[5]   # senders send rows they own
     # too-thin strips: no plan (a strip must hold the rows it sends to both neighbours)
     assert P.strip_plan(64, 4, 0, halo=True) is None
+
+
+def test_strip_planning_for_several_mask_regions():
+    """Strips x regions (nn/engine.py): every region's index set is ordered by the strip that owns each sample's row;
+    the blocks of one rank over all regions partition that rank's samples, and nothing is lost or duplicated."""
+    import numpy as np
+    from nn import parallel, strotss_utils as SU
+    h, w, world, regions = 512, 96, 4, 3
+    plans = [parallel.strip_plan(h, world, r, margin=32) for r in range(world)]
+    assert all(p is not None for p in plans) and all(p.bounds == plans[0].bounds for p in plans)
+    rng = np.random.default_rng(1)
+    edges = [round(r * w / regions) for r in range(regions + 1)]
+    for a, b in zip(edges, edges[1:]):
+        m = np.zeros((h, w), dtype=bool); m[:, a:b] = True
+        idx = SU.make_indices_np(h, w, True, 256, rng, m)
+        srt, off = parallel.sort_indices_by_strip(idx, plans[0])
+        assert off[0] == 0 and off[-1] == len(idx) and len(off) == world + 1
+        assert sorted(map(tuple, srt.tolist())) == sorted(map(tuple, idx.tolist()))          # a permutation
+        for r in range(world):
+            rows = srt[off[r]:off[r + 1], 0]
+            assert ((rows >= plans[r].own0) & (rows < plans[r].own1)).all()
+            assert ((srt[off[r]:off[r + 1], 1] >= a) & (srt[off[r]:off[r + 1], 1] < b)).all()  # and still inside its region

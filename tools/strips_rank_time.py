@@ -49,7 +49,7 @@ def main():
             step = lambda i: eng.step([idx[i % 16]], offs[i % 16])
             # stand-in for the feature all-reduce: the other ranks' rows come from the unsharded engine's matrix (left
             # zero they would tie every relaxed-EMD minimum and distort the loss kernels' time)
-            parallel.allreduce_sum_ = (lambda e, ref: (lambda t, group=None: t.copy_(ref) if t is e.pf[0] else t))(eng, ref_pf)
+            parallel.allreduce_sum_ = (lambda e, ref: (lambda t, group=None: t.copy_(ref) if t is e._pf_all else t))(eng, ref_pf)
         for i in range(3):
             step(i)
         torch.cuda.synchronize()
@@ -61,7 +61,7 @@ def main():
         ms = (time.perf_counter() - t0) / n * 1e3
         base = base or ms
         if plan is None:
-            ref_pf = eng.pf[0].clone()
+            ref_pf = eng._pf_all.clone()
         rows = S if plan is None else plan.win1 - plan.win0
         if halo and plan is not None:
             print(f"    ({eng._halo.messages // 2 // 23} neighbour exchanges per step, stubbed) ", end="")

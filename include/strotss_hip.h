@@ -73,9 +73,18 @@ int strotss_resize_bilinear_adjoint(const float* gout, int oh, int ow, int c, fl
  *   out(h,w,cout) = relu(conv3x3((img-mean)/std zero-padded, w_kio) + bias), img(h,w,3) in [0,1].
  *   w_kio: (27, cout) = HWIO kernel flattened, k = (dy*3+dx)*3+ci.
  *   mean3/std3 are the ONLY host pointers of this ABI: 3 floats each, the constants of
- *   model.py:34-35, read at call time and passed to the kernel by value. */
+ *   model.py:34-35, read at call time and passed to the kernel by value.
+ *   relu_bits_out (may be NULL): also writes the sign words of `out`, see strotss_relu_bits. */
 int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, const float* bias,
-                           int cout, const float* mean3, const float* std3, float* out, void* stream);
+                           int cout, const float* mean3, const float* std3, float* out,
+                           unsigned int* relu_bits_out, void* stream);
+/* Sign words of a conv layer's output on the F(4x4,3x3) tile grid: what the data-gradient of the NEXT layer needs of it
+ * (the ReLU mask, model.py:44-48 differentiated) in 4 bytes per (4 x 4 tile, channel) instead of 64:
+ *   relu_bits[(ty * TW + tx) * c + ch], TW = (w + 3) / 4, byte r (0..3), bit q (0..3) = act[4 ty + r][4 tx + q][ch] > 0
+ * (pixels outside the image: unspecified).  strotss_relu_bits_bytes(h, w, c) bytes.  The forward entry points write
+ * them from registers (relu_bits_out); strotss_relu_bits derives them from a finished activation tensor (h, w, c). */
+size_t strotss_relu_bits_bytes(int h, int w, int c);
+int strotss_relu_bits(const float* act, int h, int w, int c, unsigned int* relu_bits, void* stream);
 /* Generic layer, cin % 32 == 0, cout % 64 == 0:
  *   out(h,w,cout) = relu(conv3x3(in(h,w,cin)) + bias);  w_tok: (9, cout, cin), tap = dy*3+dx. */
 /* workspace (may be NULL; strotss_conv3x3_workspace_bytes(h, w, cin, cout) bytes, 0 for big maps): with it, layers of at
@@ -132,17 +141,20 @@ int strotss_conv3x3_winograd_x3pack(const float* u_prk, int rows, int k, void* u
 /* u_prk: (36, rows, k) -> u_packed[p][rows/32][k/8][2][32][4]: element (p, r, c) at
  * ((((p * (rows/32) + r/32) * (k/8) + c/8) * 2 + (c%8)/4) * 32 + r%32) * 4 + c%4.  rows % 32 == 0, k % 8 == 0. */
 int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_packed, void* stream);
-/* pool_out (may be NULL): also writes strotss_maxpool2_fwd(out) = the (h/2, w/2, cout) input of the next block --
+/* relu_bits_out (fwd, may be NULL, tile_m == 4 only): also writes the sign words of `out` (strotss_relu_bits).
+ * relu_bits (dgrad, may be NULL, tile_m == 4 only): the sign words of the layer's INPUT activation; when given, the ReLU
+ * mask comes from them and act_in is not read (same result bit for bit: 4 bytes per tile and channel instead of 64).
+ * pool_out (may be NULL): also writes strotss_maxpool2_fwd(out) = the (h/2, w/2, cout) input of the next block --
  * from the registers of the fused kernel's epilogue where that kernel runs, by a pooling launch otherwise;
  * pool_code (may be NULL, needs pool_out): the argmax codes of that pooling, see strotss_maxpool2_fwd. */
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok,
                                  const float* u_packed, const void* u_x3, const float* bias,
                                  int cout, int tile_m, float* out,
-                                 float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
-                                 void* stream);
+                                 float* pool_out, unsigned char* pool_code, unsigned int* relu_bits_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
                                    const float* u_packed, const void* u_x3, int cin, int tile_m,
-                                   const float* act_in, float* gin,
+                                   const float* act_in, const unsigned int* relu_bits, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream);
 /* Which kernels strotss_conv3x3_winograd_fwd / _dgrad run for a layer shape (the routing is a size policy with
  * environment switches, read once per process): what bench.py names in its roofline.  has_packed / has_x3: whether the

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_dgrad_kernel(const float* __re
 __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* __restrict__ img, int H, int W,
                                                                   const float* __restrict__ w_kio,
                                                                   const float* __restrict__ bias,
-                                                                  f32x4 mean_, f32x4 istd_, float* __restrict__ out) {
+                                                                  f32x4 mean_, f32x4 istd_, float* __restrict__ out,
+                                                                  unsigned char* __restrict__ bits_out) {
   __shared__ float wsm[28 * 64];
   __shared__ float patch[3 * C3F_PW * 3];
   __shared__ __attribute__((aligned(16))) float stage[4 * 32 * C3F_RS];
@@ -542,6 +543,25 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_mfma_kernel(const float* _
       const float w0 = wsm[(2 * s2 + hh) * 64 + l31], w1 = wsm[(2 * s2 + hh) * 64 + 32 + l31];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc1, 0, 0, 0);
+    }
+    if (bits_out) {
+      // sign words of the F(4x4) tile grid (include/strotss_hip.h: relu_bits): this image row is byte y % 4 of its tiles'
+      // words; registers 4g .. 4g + 3 of a lane are the 4 pixels of tile 2g + hh of the wave's eight, channel l31 (+ 32)
+      unsigned char* brow = bits_out + ((size_t)(y >> 2) * ((W + 3) >> 2) + (xw >> 2)) * 256 + (y & 3);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int tl = 2 * g + hh;
+        if (xw + 4 * tl < W) {
+          unsigned n0 = 0, n1 = 0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            n0 |= (acc0[4 * g + c] > 0.f ? 1u : 0u) << c;
+            n1 |= (acc1[4 * g + c] > 0.f ? 1u : 0u) << c;
+          }
+          brow[(tl * 64 + l31) * 4] = (unsigned char)n0;
+          brow[(tl * 64 + 32 + l31) * 4] = (unsigned char)n1;
+        }
+      }
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -751,12 +771,40 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
   }
 }
 
+// sign words (include/strotss_hip.h: relu_bits) from a finished activation tensor: thread = (tile, channel)
+__global__ __launch_bounds__(256) void relu_bits_kernel(const float* __restrict__ act, int H, int W, int C, size_t total,
+                                                       unsigned* __restrict__ bits) {
+  const int TW = (W + 3) >> 2;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const size_t tile = e / C;
+    const int ty = (int)(tile / TW), tx = (int)(tile - (size_t)ty * TW);
+    unsigned wv = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int y = 4 * ty + r, x = 4 * tx + q;
+        if (y < H && x < W && act[((size_t)y * W + x) * C + c] > 0.f) wv |= 1u << (8 * r + q);
+      }
+    bits[e] = wv;
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
+int strotss_relu_bits(const float* act, int h, int w, int c, unsigned int* relu_bits, void* stream) {
+  ST_CHECK_ARG(act && relu_bits && h > 0 && w > 0 && c > 0, STROTSS_EINVAL);
+  const size_t total = (size_t)((h + 3) / 4) * ((w + 3) / 4) * c;
+  hipLaunchKernelGGL(relu_bits_kernel, dim3((unsigned)min((size_t)8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     act, h, w, c, total, relu_bits);
+  ST_LAUNCH_RET();
+}
+
 int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, const float* bias, int cout,
-                           const float* mean3, const float* std3, float* out, void* stream) {
+                           const float* mean3, const float* std3, float* out, unsigned int* relu_bits_out, void* stream) {
   ST_CHECK_ARG(img && w_kio && bias && mean3 && std3 && out && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(cout >= 16 && cout <= 256 && (cout & (cout - 1)) == 0, STROTSS_EALIGN);
   const f32x4 m = {mean3[0], mean3[1], mean3[2], 0.f};
@@ -764,12 +812,13 @@ int strotss_conv3x3_c3_fwd(const float* img, int h, int w, const float* w_kio, c
   if (cout == 64 && conv_variant() != 1) {
     const int trips = h * cdiv(w, C3F_SEG);
     hipLaunchKernelGGL(conv3x3_c3_fwd_mfma_kernel, dim3(min(2048, trips)), dim3(256), 0, (hipStream_t)stream,
-                       img, h, w, w_kio, bias, m, is, out);
+                       img, h, w, w_kio, bias, m, is, out, (unsigned char*)relu_bits_out);
     ST_LAUNCH_RET();
   }
   const int ppb = 256 / (cout >> 4);
   hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(cdiv((int64_t)h * w, ppb)), dim3(256),
                      27 * cout * sizeof(float), (hipStream_t)stream, img, h, w, w_kio, bias, cout, m, is, out);
+  if (relu_bits_out) return strotss_relu_bits(out, h, w, cout, relu_bits_out, stream);
   ST_LAUNCH_RET();
 }
 

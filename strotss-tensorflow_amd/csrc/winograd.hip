@@ -226,8 +226,11 @@ __global__ __launch_bounds__(256) void winograd43_in_x3_kernel(const float* __re
 __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __restrict__ Mw, int H, int W, int C4,
                                                              int TH, int TW, const float* __restrict__ bias,
                                                              const float* __restrict__ mask, int relu,
-                                                             float* __restrict__ out, int c4_shift, size_t Tstride) {
+                                                             float* __restrict__ out, int c4_shift, size_t Tstride,
+                                                             const u32x4* __restrict__ bits_in, u32x4* __restrict__ bits_out) {
   // Tstride: tiles per position plane of Mw (>= TH * TW: the streaming GEMM pads the planes to whole 128-row tiles)
+  // bits_in / bits_out: sign words of the tile grid (include/strotss_hip.h: relu_bits), one per (tile, channel); with
+  // bits_in the mask comes from them (16 bytes per thread instead of 16 x 16 bytes of activations)
   const size_t T = (size_t)TH * TW;
   const unsigned total = (unsigned)(T * C4);
   const f32x4* src = reinterpret_cast<const f32x4*>(Mw);
@@ -250,6 +253,8 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
     }
     f32x4 b = {0.f, 0.f, 0.f, 0.f};
     if (bias) b = reinterpret_cast<const f32x4*>(bias)[c];
+    u32x4 kw = {0u, 0u, 0u, 0u}, ow = {0u, 0u, 0u, 0u};
+    if (bits_in) kw = bits_in[e];                      // e = tile * C4 + c
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int y = 4 * ty + r;
@@ -265,8 +270,15 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
         if (x >= W) continue;
         f32x4 v = yv[q];
         const size_t o = ((size_t)y * W + x) * C4 + c;
+        if (bits_out) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ow[j] |= (v[j] > 0.f ? 1u : 0u) << (8 * r + q);
+        }
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        if (mask) {
+        if (bits_in) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ((kw[j] >> (8 * r + q)) & 1u) ? v[j] : 0.f;
+        } else if (mask) {
           const f32x4 k = msk[o];
           v[0] = k[0] > 0.f ? v[0] : 0.f; v[1] = k[1] > 0.f ? v[1] : 0.f;
           v[2] = k[2] > 0.f ? v[2] : 0.f; v[3] = k[3] > 0.f ? v[3] : 0.f;
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
         dst[o] = v;
       }
     }
+    if (bits_out) bits_out[e] = ow;
   }
 }
 
@@ -319,12 +332,12 @@ static int g_wino_stages = 7;
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* Upacked,
                           const void* Ux3, const float* bias, int cout, const float* mask, int relu, float* out,
                           float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
-                          hipStream_t st) {
+                          hipStream_t st, const unsigned* bits_in = nullptr, unsigned* bits_out = nullptr) {
   // 256 output channels and enough tiles for the bf16x3 GEMMs: the three-kernel form wins (1024-px step 5.102 -> 5.039 ms,
   // three alternating runs each); STROTSS_X3_MIN_COUT (default 256) moves the border
   const bool prefer_x3 = Ux3 && cin % 32 == 0 && winograd43_prefers_x3(h, w, cout);
   if (!prefer_x3 && Upacked && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout))      // everything on chip
-    return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, st);
+    return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, bits_in, bits_out, st);
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const size_t T = (size_t)TH * TW;
   const bool x3 = Ux3 && cin % 32 == 0 && x3_enabled(T, cout);
@@ -344,7 +357,7 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
                        in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V), log2_or_minus1(cin / 32));
     // two-kernel form: the GEMMs of all 36 positions and the output transform in ONE kernel, no M tensor
     if (st_winograd43_gemm_out_enabled(T, cin, cout))
-      return (stages & 2) ? st_winograd43_gemm_out(V, Ux3, T, cin, cout, h, w, TW, bias, mask, relu, out, st) : 0;
+      return (stages & 2) ? st_winograd43_gemm_out(V, Ux3, T, cin, cout, h, w, TW, bias, mask, relu, out, bits_in, bits_out, st) : 0;
     if (!(stages & 2)) rc = 0;
     else if (st_gemm_x3_stream_ok((int)T, cout, cin, 36)) {          // one persistent pipeline per CU over all 36 x tiles
       Tstride = Tpad;
@@ -361,7 +374,8 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
   }
   if (rc != 0) return rc;
   if (stages & 4) hipLaunchKernelGGL(winograd43_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
-                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out, log2_or_minus1(cout / 4), Tstride);
+                     Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out, log2_or_minus1(cout / 4), Tstride,
+                     reinterpret_cast<const u32x4*>(bits_in), reinterpret_cast<u32x4*>(bits_out));
   ST_LAUNCH_RET();
 }
 
@@ -446,6 +460,10 @@ int strotss_conv3x3_winograd_weights(const float* g_nk33, int n, int k, int tile
   ST_LAUNCH_RET();
 }
 
+size_t strotss_relu_bits_bytes(int h, int w, int c) {
+  return (size_t)((h + 3) / 4) * ((w + 3) / 4) * (size_t)c * sizeof(unsigned int);
+}
+
 size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout, int tile_m) {
   if (tile_m == 4) {
     const size_t T4 = (size_t)((h + 3) / 4) * ((w + 3) / 4);
@@ -457,8 +475,10 @@ size_t strotss_conv3x3_winograd_workspace_bytes(int h, int w, int cin, int cout,
 
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok, const float* u_packed,
                                  const void* u_x3, const float* bias, int cout, int tile_m, float* out, float* pool_out,
-                                 unsigned char* pool_code, void* workspace, size_t workspace_bytes, void* stream) {
+                                 unsigned char* pool_code, unsigned int* relu_bits_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(in && u_pok && bias && out && workspace && h > 0 && w > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(!relu_bits_out || tile_m == 4, STROTSS_EINVAL);
   ST_CHECK_ARG(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   ST_CHECK_ARG(!pool_out || (h >= 2 && w >= 2), STROTSS_EINVAL);
@@ -468,7 +488,7 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
   int rc;
   if (tile_m == 4)
     rc = winograd43_run(in, h, w, cin, u_pok, u_packed, u_x3, bias, cout, nullptr, 1, out, pool_out, pool_code, workspace,
-                        workspace_bytes, (hipStream_t)stream);
+                        workspace_bytes, (hipStream_t)stream, nullptr, relu_bits_out);
   else
     rc = winograd_run(in, h, w, cin, u_pok, bias, cout, nullptr, 1, out, workspace, workspace_bytes,
                       (hipStream_t)stream);
@@ -478,14 +498,15 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
 
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
                                    const float* u_packed, const void* u_x3, int cin, int tile_m,
-                                   const float* act_in, float* gin,
+                                   const float* act_in, const unsigned int* relu_bits, float* gin,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(gout && u_pik && gin && workspace && h > 0 && w > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(!relu_bits || tile_m == 4, STROTSS_EINVAL);
   ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   if (tile_m == 4)
     return winograd43_run(gout, h, w, cout, u_pik, u_packed, u_x3, nullptr, cin, act_in, 0, gin, nullptr, nullptr, workspace,
-                          workspace_bytes, (hipStream_t)stream);
+                          workspace_bytes, (hipStream_t)stream, relu_bits, nullptr);
   return winograd_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
                       (hipStream_t)stream);
 }

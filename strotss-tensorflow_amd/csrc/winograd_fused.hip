@@ -91,7 +91,8 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ mask, int relu,
                                                                 float* __restrict__ out, float* __restrict__ pool, unsigned char* __restrict__ pool_code, int RW,
-                                                                int NG, int nitems) {
+                                                                int NG, int nitems, const unsigned* __restrict__ bits_in,
+                                                                unsigned* __restrict__ bits_out) {
   __shared__ __attribute__((aligned(16))) float lds[F_LDS_FLOATS];
   float* const Vb = lds;                            // V[2]
   float* const Rb = lds + 2 * F_V;                  // raw[2]
@@ -349,7 +350,12 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
         const size_t ob = tile_in ? ((size_t)yb * W + xb) * Cout + co : (size_t)co;
         float* op = out + ob;
         unsigned keep = 0xffffu;
-        if constexpr (MASK) {
+        // sign words of the tile grid (include/strotss_hip.h: relu_bits): one word per (tile, channel), byte r = row r
+        const size_t bo = ((size_t)(yb >> 2) * ((W + 3) >> 2) + (xb >> 2)) * Cout + co;
+        if (MASK && bits_in) {                       // 4 bytes instead of 16 activations
+          const unsigned wv = bits_in[tile_in ? bo : 0];
+          keep = (wv & 0xfu) | ((wv >> 4) & 0xf0u) | ((wv >> 8) & 0xf00u) | ((wv >> 12) & 0xf000u);
+        } else if constexpr (MASK) {
           const float* mp = mask + ob;
           float mk[4][4];
 #pragma unroll
@@ -380,6 +386,14 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
                 op[(r * W + c) * Cout] = ((keep >> (4 * r + c)) & 1u) ? fmaxf(Y[i][r][c], lo) : 0.f;
         }
         if constexpr (!MASK) {
+          if (bits_out && tile_in) {
+            unsigned wv = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) wv |= (Y[i][r][c] > 0.f ? 1u : 0u) << (8 * r + c);
+            bits_out[bo] = wv;
+          }
           // fused 2x2/2 max-pool of the activations just written (the tile's 4x4 outputs hold 2x2 windows);
           // windows are emitted only where they lie inside the image (floor pooling)
           if (pool) {
@@ -453,7 +467,7 @@ bool st_winograd43_fused_enabled(int h, int w, int cout) {
 
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                         const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code,
-                        hipStream_t st) {
+                        const unsigned* bits_in, unsigned* bits_out, hipStream_t st) {
   if (cin % 32 != 0 || cout % 32 != 0) return STROTSS_EALIGN;
   if ((size_t)h * w * cin >= ((size_t)1 << 30) || (size_t)h * w * cout >= ((size_t)1 << 30)) return STROTSS_EALIGN;
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
@@ -470,8 +484,8 @@ int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, 
   int grid = cus;                                  // persistent: one 147 KB-LDS workgroup per CU, a multiple of 8
   while (grid > 8 && grid / 2 >= nitems) grid /= 2;
 #define LAUNCH_FUSED(M) hipLaunchKernelGGL((winograd43_fused_kernel<M>), dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, \
-                                           cin, U, cout, bias, mask, relu, out, pool_out, pool_code, RW, NG, nitems)
-  if (mask) LAUNCH_FUSED(true); else LAUNCH_FUSED(false);
+                                           cin, U, cout, bias, mask, relu, out, pool_out, pool_code, RW, NG, nitems, bits_in, bits_out)
+  if (mask || bits_in) LAUNCH_FUSED(true); else LAUNCH_FUSED(false);
 #undef LAUNCH_FUSED
   ST_LAUNCH_RET();
 }

@@ -78,6 +78,8 @@ __global__ __launch_bounds__(256) void winograd43_gemm_out_kernel(const __bf16* 
                                                                   int T, int K, int N, int H, int W, int TW,
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ mask, int relu,
+                                                                  const unsigned* __restrict__ bits_in,
+                                                                  unsigned* __restrict__ bits_out,
                                                                   float* __restrict__ out, int nitems, int nb) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * GO_STAGE];
   constexpr int D = NS - 1;                                      // tiles in flight
@@ -218,6 +220,9 @@ __global__ __launch_bounds__(256) void winograd43_gemm_out_kernel(const __bf16* 
       const int tile = m0 + wm * 32 + 8 * (e >> 2) + 4 * hh + (e & 3);
       if (tile >= T) continue;
       const int ty = tile / TW, tx = tile - ty * TW;
+      // sign words of the tile grid (include/strotss_hip.h: relu_bits): one per (tile, channel), byte i = row i
+      const unsigned kw = (MASK && bits_in) ? bits_in[(size_t)tile * N + n] : 0u;
+      unsigned ow = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int y = 4 * ty + i;
@@ -228,11 +233,12 @@ __global__ __launch_bounds__(256) void winograd43_gemm_out_kernel(const __bf16* 
           if (x >= W) continue;
           const size_t o = ((size_t)y * W + x) * N + n;
           float v = Y[i][j][e];
-          if (MASK) v = mask[o] > 0.f ? v : 0.f;
-          else { v += bv; if (relu) v = fmaxf(v, 0.f); }
+          if (MASK) v = (bits_in ? ((kw >> (8 * i + j)) & 1u) != 0u : mask[o] > 0.f) ? v : 0.f;
+          else { v += bv; ow |= (v > 0.f ? 1u : 0u) << (8 * i + j); if (relu) v = fmaxf(v, 0.f); }
           out[o] = v;
         }
       }
+      if (!MASK && bits_out) bits_out[(size_t)tile * N + n] = ow;
     }
     __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring before it is refilled
   }
@@ -267,7 +273,8 @@ bool st_winograd43_gemm_out_enabled(size_t T, int cin, int cout) {
 }
 
 int st_winograd43_gemm_out(const void* V, const void* Ux3, size_t T, int cin, int cout, int h, int w, int TW,
-                           const float* bias, const float* mask, int relu, float* out, hipStream_t st) {
+                           const float* bias, const float* mask, int relu, float* out, const unsigned* bits_in,
+                           unsigned* bits_out, hipStream_t st) {
   const int nb = cout / 64;
   const size_t items = ((T + 63) / 64) * (size_t)nb;
   if (items >= ((size_t)1 << 30)) return STROTSS_ERANGE;
@@ -276,11 +283,11 @@ int st_winograd43_gemm_out(const void* V, const void* Ux3, size_t T, int cin, in
   if (grid > nitems) grid = nitems;
   const __bf16* v = reinterpret_cast<const __bf16*>(V);
   const __bf16* u = reinterpret_cast<const __bf16*>(Ux3);
-  if (mask)
+  if (mask || bits_in)
     hipLaunchKernelGGL((winograd43_gemm_out_kernel<true, 5>), dim3((unsigned)grid), dim3(256), 0, st, v, u, (int)T, cin, cout,
-                       h, w, TW, bias, mask, relu, out, nitems, nb);
+                       h, w, TW, bias, mask, relu, bits_in, bits_out, out, nitems, nb);
   else
     hipLaunchKernelGGL((winograd43_gemm_out_kernel<false, 5>), dim3((unsigned)grid), dim3(256), 0, st, v, u, (int)T, cin, cout,
-                       h, w, TW, bias, mask, relu, out, nitems, nb);
+                       h, w, TW, bias, mask, relu, bits_in, bits_out, out, nitems, nb);
   ST_LAUNCH_RET();
 }

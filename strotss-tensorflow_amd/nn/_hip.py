@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STROTSS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libstrotss_hip.so")
 
 MAX_MAPS, MAX_DIVS, MAX_TENSORS = 12, 8, 8
-ABI_VERSION = 4          # must equal strotss_abi_version() of the loaded library (argument lists change with it)
+ABI_VERSION = 5          # must equal strotss_abi_version() of the loaded library (argument lists change with it)
 
 
 class StrotssHipError(RuntimeError):
@@ -53,7 +53,9 @@ SIGNATURES = {
     "strotss_resize_bilinear": (_I, [_P, _I, _I, _I, _P, _I, _I, _F, _P, _P]),
     "strotss_fold_pyramid": (_I, [C.POINTER(PyramidT), _P, _P]),
     "strotss_resize_bilinear_adjoint": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
-    "strotss_conv3x3_c3_fwd": (_I, [_P, _I, _I, _P, _P, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
+    "strotss_conv3x3_c3_fwd": (_I, [_P, _I, _I, _P, _P, _I, C.POINTER(_F), C.POINTER(_F), _P, _P, _P]),
+    "strotss_relu_bits_bytes": (_Z, [_I, _I, _I]),
+    "strotss_relu_bits": (_I, [_P, _I, _I, _I, _P, _P]),
     "strotss_conv3x3_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "strotss_conv3x3_relu_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "strotss_conv3x3_dgrad": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
@@ -63,8 +65,8 @@ SIGNATURES = {
     "strotss_conv3x3_winograd_pack": (_I, [_P, _I, _I, _P, _P]),
     "strotss_conv3x3_winograd_x3_bytes": (_Z, [_I, _I]),
     "strotss_conv3x3_winograd_x3pack": (_I, [_P, _I, _I, _P, _P]),
-    "strotss_conv3x3_winograd_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
-    "strotss_conv3x3_winograd_dgrad": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _P]),
+    "strotss_conv3x3_winograd_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "strotss_conv3x3_winograd_dgrad": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "strotss_conv3x3_winograd_route": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "strotss_debug_winograd_stages": (_I, [_I]),
     "strotss_maxpool2_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),

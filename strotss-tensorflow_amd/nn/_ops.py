@@ -82,14 +82,28 @@ def _f3(v, default):
     return default if v is None else (C.c_float * 3)(*v)
 
 
-def conv3x3_c3_fwd(img, w_kio, bias, out=None, mean=None, std=None):
+def relu_bits_buffer(h: int, w: int, c: int, device) -> torch.Tensor:
+    """Room for the sign words of an (h, w, c) activation: one int32 per (4x4 tile, channel), see include/strotss_hip.h."""
+    return torch.empty(((h + 3) // 4) * ((w + 3) // 4), c, dtype=torch.int32, device=device)
+
+
+def relu_bits(act, out=None):
+    """Sign words of a finished activation tensor (1, h, w, c): byte r, bit q of word (tile, ch) = act[4ty+r, 4tx+q, ch] > 0."""
+    require(act, "activation"); h, w, c = hwc(act)
+    if out is None:
+        out = relu_bits_buffer(h, w, c, act.device)
+    check(_hip.lib().strotss_relu_bits(ptr(act), h, w, c, ptr(out), stream_ptr()), "relu_bits")
+    return out
+
+
+def conv3x3_c3_fwd(img, w_kio, bias, out=None, mean=None, std=None, relu_bits_out=None):
     require(img, "image"); h, w, c = hwc(img)
     assert c == 3
     cout = bias.numel()
     if out is None:
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=img.device)
     check(_hip.lib().strotss_conv3x3_c3_fwd(ptr(img), h, w, ptr(w_kio), ptr(bias), cout, _f3(mean, _MEAN3),
-                                            _f3(std, _STD3), ptr(out), stream_ptr()), "conv3x3_c3_fwd")
+                                            _f3(std, _STD3), ptr(out), ptr(relu_bits_out), stream_ptr()), "conv3x3_c3_fwd")
     return out
 
 
@@ -201,9 +215,10 @@ def winograd_x3(u: torch.Tensor, h: int, w: int):
     return up
 
 
-def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None):
+def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None, relu_bits_out=None):
     """u_pok: (16, cout, cin) -> F(2x2,3x3), (36, cout, cin) -> F(4x4,3x3).  pool_out: (1, h//2, w//2, cout) buffer
-    that also receives the 2x2/2 max-pool of the result."""
+    that also receives the 2x2/2 max-pool of the result.  relu_bits_out (F(4x4) only): relu_bits_buffer that receives the
+    sign words of the result, for the next layer's conv3x3_winograd_dgrad."""
     require(x, "conv input"); h, w, cin = hwc(x)
     cout = bias.numel()
     if out is None:
@@ -213,12 +228,15 @@ def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None
     ws, nb = _wino_ws(h, w, cin, cout, m, x.device)
     check(_hip.lib().strotss_conv3x3_winograd_fwd(ptr(x), h, w, cin, ptr(u_pok), ptr(winograd_packed(u_pok)),
                                                   ptr(winograd_x3(u_pok, h, w)), ptr(bias),
-                                                  cout, m, ptr(out), ptr(pool_out), ptr(pool_code), ptr(ws), nb, stream_ptr()),
+                                                  cout, m, ptr(out), ptr(pool_out), ptr(pool_code), ptr(relu_bits_out), ptr(ws), nb,
+                                                  stream_ptr()),
           "conv3x3_winograd_fwd")
     return out
 
 
-def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
+def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None, relu_bits=None):
+    """relu_bits (F(4x4) only): the sign words of the layer's input activation; the ReLU mask then comes from them instead of
+    act_in (same result, 1/16 of the bytes)."""
     require(gout, "conv grad"); h, w, cout = hwc(gout)
     if out is None:
         out = torch.empty((1, h, w, cin), dtype=torch.float32, device=gout.device)
@@ -227,7 +245,7 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None):
     ws, nb = _wino_ws(h, w, cout, cin, m, gout.device)
     check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), ptr(winograd_packed(u_pik)),
                                                     ptr(winograd_x3(u_pik, h, w)), cin,
-                                                    m, ptr(act_in), ptr(out), ptr(ws), nb, stream_ptr()),
+                                                    m, ptr(act_in), ptr(relu_bits), ptr(out), ptr(ws), nb, stream_ptr()),
           "conv3x3_winograd_dgrad")
     return out
 

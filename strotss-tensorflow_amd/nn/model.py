@@ -248,9 +248,20 @@ class VGGTrunk:
         # Winograd tile per layer for this image size
         self.wtile = [winograd_tile(int(a.shape[1]), int(a.shape[2]), L["cin"], L["cout"]) if "u_fwd" in L else 0
                       for L, a in zip(params.layers, self.acts)]
+        self.relu_bits = [None] * len(self.acts)
         if with_grad:
             # argmax codes of the pools (1 byte per pooled element): the backward pass reads them, not the activations
             self.pool_codes = [torch.empty(p.shape, dtype=torch.uint8, device=dev) for p in self.pools]
+            # sign words of the activations whose ReLU mask an F(4x4,3x3) data-gradient applies: 4 bytes per 4x4 tile and
+            # channel, written by the producing forward kernel from registers, instead of re-reading the f32 activation
+            # (268 MB for block1_conv1 at 1024^2).  Not with a halo exchange: it rewrites border rows of the activations.
+            if halo is None and os.environ.get("STROTSS_RELU_BITS", "1") != "0":
+                for step in self.plan:
+                    if step[0] == 'conv' and step[2][0] == 'conv' and self.wtile[step[1]] == 4:
+                        si = step[2][1]
+                        if self.wtile[si] == 4 or params.layers[si]["cin"] == 3:
+                            a = self.acts[si]
+                            self.relu_bits[si] = _ops.relu_bits_buffer(int(a.shape[1]), int(a.shape[2]), int(a.shape[3]), dev)
             # Small maps ("pre-scatter" backward): when EVERY tapped layer's gradient is produced by a kernel that can
             # add to its output (the split-K direct data-gradient, the pooling backward, the first layer's pixel
             # gradient), the taps of all maps are scattered in ONE launch into zeroed buffers before the backward pass
@@ -302,7 +313,8 @@ class VGGTrunk:
                 L = P.layers[li]
                 x = self._src(src)
                 if L["cin"] == 3:
-                    _ops.conv3x3_c3_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li], mean=P.mean, std=P.std)
+                    _ops.conv3x3_c3_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li], mean=P.mean, std=P.std,
+                                        relu_bits_out=self.relu_bits[li])
                 elif self.wtile[li]:
                     nxt = self.plan[si + 1] if si + 1 < len(self.plan) else None
                     pool_out = pool_code = None
@@ -311,7 +323,7 @@ class VGGTrunk:
                         pool_code = self.pool_codes[nxt[1]] if self.with_grad else None
                         pooled.add(nxt[1])
                     _ops.conv3x3_winograd_fwd(x, L["u_fwd"][self.wtile[li]], L["bias"], out=self.acts[li],
-                                              pool_out=pool_out, pool_code=pool_code)
+                                              pool_out=pool_out, pool_code=pool_code, relu_bits_out=self.relu_bits[li])
                 else:
                     _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
                 if self.halo is not None:     # (the pooling launch that may follow then reads right rows only)
@@ -358,6 +370,9 @@ class VGGTrunk:
                     if kind == 'conv':
                         if pre and si in tapped:
                             dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si], accumulate=True)
+                        elif wino and self.relu_bits[si] is not None:
+                            dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si],
+                                  relu_bits=self.relu_bits[si])
                         else:
                             dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si])
                         if si in tapped:

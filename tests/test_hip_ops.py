@@ -77,6 +77,31 @@ def _conv_ref(x, w, b, relu=True):
     return (torch.relu(y) if relu else y).permute(0, 2, 3, 1)
 
 
+def _sign_words_ref(act):
+    """relu_bits of include/strotss_hip.h from an (h, w, c) array: word (tile, ch), byte r, bit q = act[4ty+r, 4tx+q, ch] > 0;
+    second result: the bits that lie inside the image (the others are unspecified)."""
+    h, w, c = act.shape
+    th, tw = (h + 3) // 4, (w + 3) // 4
+    pad = np.zeros((th * 4, tw * 4, c), dtype=bool)
+    pad[:h, :w] = act > 0
+    inside = np.zeros((th * 4, tw * 4, c), dtype=bool)
+    inside[:h, :w] = True
+    words = np.zeros((th * tw, c), dtype=np.int64)
+    valid = np.zeros((th * tw, c), dtype=np.int64)
+    for r in range(4):
+        for q in range(4):
+            words |= pad[r::4, q::4].reshape(th * tw, c).astype(np.int64) << (8 * r + q)
+            valid |= inside[r::4, q::4].reshape(th * tw, c).astype(np.int64) << (8 * r + q)
+    return words, valid
+
+
+def _check_sign_words(bits, act):
+    want, valid = _sign_words_ref(act)
+    got = bits.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert got.shape == want.shape
+    assert np.array_equal(got & valid, want), int(((got & valid) != want).sum())
+
+
 @pytest.mark.parametrize("hw", [(16, 24), (5, 7), (33, 20)])
 def test_conv_first_layer(ops, hw):
     h, w = hw
@@ -88,6 +113,11 @@ def test_conv_first_layer(ops, hw):
     xin = x.clone().requires_grad_(True)
     y = _conv_ref((xin - mean) / std, wt, b)
     got = ops.conv3x3_c3_fwd(dev(x), dev(wt.reshape(27, 64)), dev(b)).cpu().numpy()
+    bits = ops.relu_bits_buffer(h, w, 64, "cuda")
+    got_b = ops.conv3x3_c3_fwd(dev(x), dev(wt.reshape(27, 64)), dev(b), relu_bits_out=bits)
+    assert torch.equal(got_b.cpu(), torch.from_numpy(got))
+    _check_sign_words(bits, got[0])                       # the sign words the kernel writes from its registers ...
+    _check_sign_words(ops.relu_bits(got_b), got[0])       # ... and the stand-alone kernel on the finished tensor
     assert rel_err(got, y.detach().numpy()) < 2e-6
     # pixel gradient (pre-ReLU grad given): conv^T then 1/std
     gy = torch.randn(1, h, w, 64, generator=g, dtype=torch.float64)
@@ -162,11 +192,20 @@ def test_conv_winograd_fwd_and_dgrad(ops, cfg, tile_m):
     ypre = _conv_ref(xin, wt, b, relu=False)
     (ypre * gy).sum().backward()
     u_b = ops.winograd_weights(wt.flip(0, 1).permute(2, 3, 0, 1), tile_m).cuda()
+    if tile_m == 4:      # sign words of the result, written by whichever kernel the route ends in (partial tiles included)
+        bits = ops.relu_bits_buffer(h, w, cout, "cuda")
+        got3 = ops.conv3x3_winograd_fwd(dev(x), u_f, dev(b), relu_bits_out=bits).cpu().numpy()
+        assert np.array_equal(got3, got)
+        _check_sign_words(bits, got[0])
     if cin % 64 == 0:
         got = ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin).cpu().numpy()
         assert rel_err(got, xin.grad.numpy()) < tol
-        got = ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin, act_in=dev(x)).cpu().numpy()
-        assert rel_err(got, (xin.grad * (x > 0)).numpy()) < tol
+        masked = ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin, act_in=dev(x))
+        assert rel_err(masked.cpu().numpy(), (xin.grad * (x > 0)).numpy()) < tol
+        if tile_m == 4:  # the mask from the input's sign words instead of the input: the same bits
+            xb = ops.relu_bits(dev(x))
+            assert torch.equal(ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin, relu_bits=xb), masked)
+            assert torch.equal(ops.conv3x3_winograd_dgrad(dev(gy), u_b, cin, act_in=dev(x), relu_bits=xb), masked)
 
 
 def test_x3_gemm_accuracy():

@@ -6,7 +6,7 @@
 r=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$r
 mkdir -p $out && cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-pyramid"
+B="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-pyramid --no-live-pmc"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $B > $out/bench_under_rocprof.json 2> $out/trace.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $B --no-families --no-graph --steps 6 > /dev/null 2> $out/fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $B --no-families --no-graph --steps 6 > /dev/null 2> $out/write.err || exit 1

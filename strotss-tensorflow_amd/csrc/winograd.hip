@@ -227,10 +227,13 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
                                                              int TH, int TW, const float* __restrict__ bias,
                                                              const float* __restrict__ mask, int relu,
                                                              float* __restrict__ out, int c4_shift, size_t Tstride,
-                                                             const u32x4* __restrict__ bits_in, u32x4* __restrict__ bits_out) {
+                                                             const u32x4* __restrict__ bits_in, u32x4* __restrict__ bits_out,
+                                                             f32x4* __restrict__ pool, unsigned* __restrict__ pool_code) {
   // Tstride: tiles per position plane of Mw (>= TH * TW: the streaming GEMM pads the planes to whole 128-row tiles)
   // bits_in / bits_out: sign words of the tile grid (include/strotss_hip.h: relu_bits), one per (tile, channel); with
   // bits_in the mask comes from them (16 bytes per thread instead of 16 x 16 bytes of activations)
+  // pool (forward): also the 2x2/2 max-pool of the result and (pool_code) its argmax codes, exactly as maxpool2_fwd_kernel
+  // would produce them from `out` -- the tile's 4 x 4 outputs hold four whole windows
   const size_t T = (size_t)TH * TW;
   const unsigned total = (unsigned)(T * C4);
   const f32x4* src = reinterpret_cast<const f32x4*>(Mw);
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
     if (bias) b = reinterpret_cast<const f32x4*>(bias)[c];
     u32x4 kw = {0u, 0u, 0u, 0u}, ow = {0u, 0u, 0u, 0u};
     if (bits_in) kw = bits_in[e];                      // e = tile * C4 + c
+    f32x4 prev[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int y = 4 * ty + r;
@@ -284,6 +288,35 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
           v[2] = k[2] > 0.f ? v[2] : 0.f; v[3] = k[3] > 0.f ? v[3] : 0.f;
         }
         dst[o] = v;
+      }
+      if (pool) {
+        if ((r & 1) == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) prev[q] = yv[q];
+        } else {
+          const int PH = H >> 1, PW = W >> 1, py = y >> 1;
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) {
+            const int px = 2 * tx + pc;
+            if (py >= PH || px >= PW) continue;
+            f32x4 pv;
+            unsigned packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v4[4] = {prev[2 * pc][j], prev[2 * pc + 1][j], yv[2 * pc][j], yv[2 * pc + 1][j]};
+              int best = 0;
+              float bv = v4[0];
+#pragma unroll
+              for (int k = 1; k < 4; ++k)
+                if (v4[k] > bv) { bv = v4[k]; best = k; }
+              pv[j] = fmaxf(bv, 0.f);
+              packed |= (unsigned)(bv > 0.f ? best : 4) << (8 * j);
+            }
+            const size_t po = ((size_t)py * PW + px) * C4 + c;
+            pool[po] = pv;
+            if (pool_code) pool_code[po] = packed;
+          }
+        }
       }
     }
     if (bits_out) bits_out[e] = ow;
@@ -357,7 +390,11 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
                        in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V), log2_or_minus1(cin / 32));
     // two-kernel form: the GEMMs of all 36 positions and the output transform in ONE kernel, no M tensor
     if (st_winograd43_gemm_out_enabled(T, cin, cout))
-      return (stages & 2) ? st_winograd43_gemm_out(V, Ux3, T, cin, cout, h, w, TW, bias, mask, relu, out, bits_in, bits_out, st) : 0;
+    {
+      rc = (stages & 2) ? st_winograd43_gemm_out(V, Ux3, T, cin, cout, h, w, TW, bias, mask, relu, out, bits_in, bits_out, st) : 0;
+      if (rc != 0 || !pool_out) return rc;
+      return st_maxpool2_fwd(out, h, w, cout, pool_out, pool_code, st);      // (that kernel's epilogue is one row of tiles wide)
+    }
     if (!(stages & 2)) rc = 0;
     else if (st_gemm_x3_stream_ok((int)T, cout, cin, 36)) {          // one persistent pipeline per CU over all 36 x tiles
       Tstride = Tpad;
@@ -373,9 +410,14 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
                                            (long long)T * cout, (int)T, cout, cin, 36, st) : 0;
   }
   if (rc != 0) return rc;
+  // STROTSS_WINO_OUT_POOL=0: the pooled copy by a pooling launch instead of the output transform's epilogue (A/B)
+  static const bool out_pools = [] { const char* v = getenv("STROTSS_WINO_OUT_POOL"); return !v || atoi(v) != 0; }();
   if (stages & 4) hipLaunchKernelGGL(winograd43_out_kernel, dim3((unsigned)min((size_t)16384, (tout + 255) / 256)), dim3(256), 0, st,
                      Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out, log2_or_minus1(cout / 4), Tstride,
-                     reinterpret_cast<const u32x4*>(bits_in), reinterpret_cast<u32x4*>(bits_out));
+                     reinterpret_cast<const u32x4*>(bits_in), reinterpret_cast<u32x4*>(bits_out),
+                     reinterpret_cast<f32x4*>(out_pools ? pool_out : nullptr),
+                     reinterpret_cast<unsigned*>(out_pools ? pool_code : nullptr));
+  if (pool_out && !out_pools) return st_maxpool2_fwd(out, h, w, cout, pool_out, pool_code, st);
   ST_LAUNCH_RET();
 }
 
@@ -483,8 +525,6 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   ST_CHECK_ARG(!pool_out || (h >= 2 && w >= 2), STROTSS_EINVAL);
   ST_CHECK_ARG(!pool_code || pool_out, STROTSS_EINVAL);
-  bool fused = tile_m == 4 && u_packed && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout);
-  if (fused && u_x3 && winograd43_prefers_x3(h, w, cout)) fused = false;
   int rc;
   if (tile_m == 4)
     rc = winograd43_run(in, h, w, cin, u_pok, u_packed, u_x3, bias, cout, nullptr, 1, out, pool_out, pool_code, workspace,
@@ -492,7 +532,7 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
   else
     rc = winograd_run(in, h, w, cin, u_pok, bias, cout, nullptr, 1, out, workspace, workspace_bytes,
                       (hipStream_t)stream);
-  if (rc != 0 || !pool_out || fused) return rc;           // the fused kernel pooled in its epilogue
+  if (rc != 0 || !pool_out || tile_m == 4) return rc;     // the F(4x4) kernels pool in their epilogues
   return st_maxpool2_fwd(out, h, w, cout, pool_out, pool_code, (hipStream_t)stream);
 }
 

@@ -741,7 +741,7 @@ def main():
     else:
         idx = index_stream(S, count, rng, dev, regions=regions)
     if not args.no_graph:
-        eng.capture_graph(list(idx[0]))
+        eng.capture_graph(list(idx[0]), offsets[0] if strips is not None else None)
 
     run_steps(eng, idx, 0, args.warmup)
     torch.cuda.synchronize()
@@ -769,7 +769,8 @@ def main():
                     f"one masked pair, {regions} mask regions dealt round-robin to {n_gpus} rank(s), trunk replicated, "
                     f"1 all-reduce of the pixel gradient per step" if args.mode == "regions" else
                     "replicas (one pair per GPU)" if n_gpus > 1 else "single GPU")
-        graph_mode = ("eager" if (args.no_graph or strips is not None) else
+        graph_mode = ("eager" if (args.no_graph or (strips is not None and eng._strip_graphs is None)) else
+                      "3 hipGraphs per step around the two all-reduces" if strips is not None else
                       "2 hipGraphs per step around the all-reduce" if (world > 1 and args.mode == "regions") else "hipGraph")
         out = {"metric": "optimisation_steps_per_sec_1024px_pair", "value": round(value, 3), "unit": "steps/s",
                "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,

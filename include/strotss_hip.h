@@ -199,6 +199,11 @@ typedef struct {
    * clamping it to the window's edge -- halo-exchange strips: every rank scatters ALL samples and keeps what lands in
    * the rows it holds.  The gather always clamps (a rank gathers its own samples, whose taps lie inside). */
   int window_drop;
+  /* gather, scatter and plan: NULL, or a DEVICE pointer to two ints {begin, end}: only the samples begin <= s < end of
+   * the n given are processed (the launch still spans all n; the gather leaves the other rows of `out` untouched).  The
+   * block of samples a rank owns changes every step (parallel.sort_indices_by_strip); read from device memory it can
+   * change between replays of a captured graph. */
+  const int* sample_range;
 } strotss_maps_t;
 /* out(rows, ld): row s < n = concat_k sample(map_k, idx[s]); bilinear != 0 -> 4-tap weights of
  * strotss_utils.py:43-70, else truncating nearest (72-75).  idx: (n,2) float32 (row, col). */

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void hypercol_gather_kernel(strotss_maps_t m, 
                                                               int bilinear, float* __restrict__ out, int ld,
                                                               int dtotal) {
   const int s = blockIdx.x;
+  if (m.sample_range && (s < m.sample_range[0] || s >= m.sample_range[1])) return;      // not this rank's sample
   const float gx = idx[2 * s], gy = idx[2 * s + 1];
   float* o = out + (size_t)s * ld;
   int off = 0;
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m,
                                                                int relu_mask_from, int map_begin,
                                                                int map_end) {
   const int s = blockIdx.x;
+  if (m.sample_range && (s < m.sample_range[0] || s >= m.sample_range[1])) return;
   const float gx = idx[2 * s], gy = idx[2 * s + 1];
   const float* g = gfeat + (size_t)s * ld;
   int off = 0;
@@ -312,10 +314,11 @@ __global__ __launch_bounds__(1024) void scatter_plan_kernel(strotss_maps_t m, co
   __shared__ int wsum[16];
   const int k = blockIdx.x, t = threadIdx.x;
   const unsigned long long INVALID = ~0ull;
+  const int s_begin = m.sample_range ? m.sample_range[0] : 0, s_end = m.sample_range ? min(n, m.sample_range[1]) : n;
   for (int e = t; e < PLAN_E; e += 1024) {
     const int s = e >> 2, q = e & 3;
     unsigned long long kk = INVALID;
-    if (s < n) {
+    if (s >= s_begin && s < s_end) {
       const SampleTap tp = sample_tap(m, k, idx[2 * s], idx[2 * s + 1], 1);
       const int ii = q == 0 ? tp.ia : q == 1 ? tp.ib : q == 2 ? tp.ic : tp.id;
       const float ww = q == 0 ? tp.wa : q == 1 ? tp.wb : q == 2 ? tp.wc : tp.wd;

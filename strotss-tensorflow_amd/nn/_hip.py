@@ -32,7 +32,7 @@ class MapsT(C.Structure):
                 ("map", C.c_void_p * MAX_MAPS),
                 ("gmap", C.c_void_p * MAX_MAPS),
                 ("row0", C.c_int * MAX_MAPS), ("rows", C.c_int * MAX_MAPS),
-                ("window_drop", C.c_int)]
+                ("window_drop", C.c_int), ("sample_range", C.c_void_p)]
 
 
 class PyramidT(C.Structure):

@@ -158,7 +158,17 @@ class StepEngine:
         self._layer_to_map[-1] = 0
         if strips is not None:            # strips shard the IMAGE: every rank runs every region's (replicated) losses
             self.my_regions, self.world = list(range(self.R)), 1
-        self._o0, self._o1, self._ns = [0] * self.R, [0] * self.R, [0] * self.R   # strips: this rank's block of each region's samples
+        self._ns = [0] * self.R
+        # strips: the block [begin, end) of each region's (owner-ordered) samples this rank gathers and scatters lives in
+        # DEVICE memory (strotss_maps_t.sample_range): it changes every step, a captured graph reads it at replay
+        self._mt_pred_own = None
+        if strips is not None:
+            self._range_dev = torch.zeros((self.R, 2), dtype=torch.int32, device=dev)
+            self._mt_pred_own = []
+            for r in range(self.R):
+                m = _hip.MapsT.from_buffer_copy(self._mt_pred)
+                m.sample_range = self._range_dev[r].data_ptr()
+                self._mt_pred_own.append(m)
         self._idx: List[Optional[torch.Tensor]] = [None] * self.R
         # deterministic mode (STROTSS_DETERMINISTIC=1): the tap adjoint as a sorted scatter, one plan per region and step
         # (no float atomics -> bitwise reproducible steps; the reference asks TF for the same: nn/rand.py:4-8)
@@ -174,6 +184,7 @@ class StepEngine:
         self.steps_done = 0
         self._graph = None
         self._graph_post = None           # sharded regions: the part of the step after the all-reduce
+        self._strip_graphs = None         # image strips: the three stages between the two all-reduces
         self._graph_idx: List[torch.Tensor] = []
         self._graph_n: List[int] = []
 
@@ -210,38 +221,29 @@ class StepEngine:
         _ops.remd_cos_fwd_bwd(st.feats, st.inv_norm, st.ns, pf, n, self.d, base, gp, sc[2:])
         _ops.palette_remd_fwd_bwd(st.feats, st.ns, pf, n, self.inv_alpha * base, gp, sc[3:])
 
-    def _scatter(self, layer_index: int):
+    def _scatter_maps(self, r: int):
+        """descriptor + sample count of region r's tap adjoint: strips (recompute margin) = this rank's block of the samples
+        (device-side range); halo-exchange strips = every sample, taps outside the window dropped; otherwise all samples."""
+        if self.strips is not None and self._halo is None:
+            return self._mt_pred_own[r], self._ns[r]
+        if self.strips is not None:
+            return self._mt_pred, self._ns[r]
+        return self._mt_pred, int(self._idx[r].shape[0])
+
+    def _scatter(self, layer_index: int, k_end: Optional[int] = None):
         k = self._layer_to_map[layer_index]
+        k_end = k + 1 if k_end is None else k_end
         for r in self.my_regions:
-            idx, gp = self._idx[r], self.gp[r]
-            if self.strips is not None and self._halo is None:   # this rank's block of samples only
-                if self._o1[r] <= self._o0[r]:
-                    continue
-                idx, gp = idx[self._o0[r]:self._o1[r]], gp[self._o0[r]:self._o1[r]]
-            elif self.strips is not None:                        # halo exchange: every sample, taps outside the window dropped
-                idx, gp = idx[:self._ns[r]], gp[:self._ns[r]]
+            mt, n = self._scatter_maps(r)
+            idx, gp = self._idx[r][:n], self.gp[r][:n]
             if self.deterministic:
-                _ops.hypercol_scatter_sorted(self._mt_pred, self._plans[r], int(idx.shape[0]), gp, relu_mask_from=1,
-                                             map_begin=k, map_end=k + 1)
+                _ops.hypercol_scatter_sorted(mt, self._plans[r], n, gp, relu_mask_from=1, map_begin=k, map_end=k_end)
             else:
-                _ops.hypercol_scatter(self.pred_maps, None, idx, gp, relu_mask_from=1, map_begin=k,
-                                      map_end=k + 1, maps_t=self._mt_pred)
+                _ops.hypercol_scatter(self.pred_maps, None, idx, gp, relu_mask_from=1, map_begin=k, map_end=k_end, maps_t=mt)
 
     def _scatter_all(self):
         """every map's taps in one launch per region (pre-scatter backward of the small scales, nn/model.py)"""
-        n_maps = len(self.pred_maps)
-        for r in self.my_regions:
-            idx, gp = self._idx[r], self.gp[r]
-            if self.strips is not None and self._halo is None:
-                if self._o1[r] <= self._o0[r]:
-                    continue
-                idx, gp = idx[self._o0[r]:self._o1[r]], gp[self._o0[r]:self._o1[r]]
-            if self.deterministic:
-                _ops.hypercol_scatter_sorted(self._mt_pred, self._plans[r], int(idx.shape[0]), gp, relu_mask_from=1,
-                                             map_begin=0, map_end=n_maps)
-            else:
-                _ops.hypercol_scatter(self.pred_maps, None, idx, gp, relu_mask_from=1, map_begin=0, map_end=n_maps,
-                                      maps_t=self._mt_pred)
+        self._scatter(-1, len(self.pred_maps))
 
     def forward_backward(self, indices: Sequence[torch.Tensor], strip_offsets: Optional[Sequence[int]] = None) -> None:
         """train_step (run_strotss.py:131-142 / 104-125): fills self.gvars and self.scalars.
@@ -249,9 +251,8 @@ class StepEngine:
         block offsets (parallel.sort_indices_by_strip); one region: the offsets list itself is accepted too."""
         assert len(indices) == self.R
         if self.strips is not None:
-            if self.R == 1 and strip_offsets is not None and not isinstance(strip_offsets[0], (list, tuple)):
-                strip_offsets = [strip_offsets]
-            self._strip_stage_a(indices, strip_offsets)
+            self._strip_inputs(indices, strip_offsets)
+            self._strip_stage_a()
             parallel.allreduce_sum_(self._pf_all, self.group)     # rows of the other ranks' samples arrive here: ONE collective
             self._strip_stage_b()
             parallel.allreduce_sum_(self.gimg_full, self.group)   # windows overlap by the margins: sum
@@ -294,13 +295,13 @@ class StepEngine:
             _ops.resize_bilinear_adjoint(self.gvars[k - 1], hk, wk, out=self.gvars[k])
 
     # ---- image strips: the step in three stages with an all-reduce between them
-    def _strip_stage_a(self, indices: Sequence[torch.Tensor], offsets: Sequence[Sequence[int]]) -> None:
-        """fold (replicated), trunk forward on the window; per region: content rows (all, from the replicated full maps),
-        prediction rows of THIS rank's samples (the others stay zero for the all-reduce)."""
+    def _strip_inputs(self, indices: Sequence[torch.Tensor], offsets) -> None:
+        """Host side of a strips step (never captured): every region's index set (ordered by owning rank) and this rank's
+        block of it, the block bounds going to device memory."""
+        if self.R == 1 and offsets is not None and not isinstance(offsets[0], (list, tuple)):
+            offsets = [offsets]
         assert offsets is not None and len(offsets) == self.R
-        self.fold_forward()
-        self.trunk.forward(self._img_window)
-        self._pf_all.zero_()
+        bounds = []
         for r in range(self.R):
             idx = _hip.require(indices[r], "indices")
             n = int(idx.shape[0])
@@ -308,35 +309,42 @@ class StepEngine:
             assert len(off) == self.strips.world + 1 and off[-1] == n
             assert 0 < n <= self.sample_size and idx.shape[1] == 2
             self._idx[r], self._ns[r] = idx, n
-            self._o0[r], self._o1[r] = int(off[self.strips.rank]), int(off[self.strips.rank + 1])
+            bounds.append((int(off[self.strips.rank]), int(off[self.strips.rank + 1])))
+        # a fresh pinned block per step (the caching host allocator hands it out again only after this copy has run: the
+        # host may be several steps ahead of the GPU)
+        host = torch.tensor(bounds, dtype=torch.int32)
+        self._range_dev.copy_(host.pin_memory() if self._range_dev.is_cuda else host, non_blocking=True)
+
+    def _strip_stage_a(self, indices=None, offsets=None) -> None:
+        """fold (replicated), trunk forward on the window; per region: content rows (all, from the replicated full maps),
+        prediction rows of THIS rank's samples (the others stay zero for the all-reduce).  Capturable: nothing here
+        depends on the block bounds on the host.  (indices, offsets given: _strip_inputs first -- the eager form.)"""
+        if indices is not None:
+            self._strip_inputs(indices, offsets)
+        self.fold_forward()
+        self.trunk.forward(self._img_window)
+        self._pf_all.zero_()
+        for r in range(self.R):
+            idx = self._idx[r]
             self._gather(self._mt_content, idx, self.cf[r])
-            if self._o1[r] > self._o0[r]:
-                _hip.check(_hip.lib().strotss_hypercol_gather(
-                    _hip.C.byref(self._mt_pred), idx[self._o0[r]:].data_ptr(), self._o1[r] - self._o0[r], 1,
-                    self.pf[r][self._o0[r]:].data_ptr(), self.ld, _hip.stream_ptr()), "hypercol_gather")
+            self._gather(self._mt_pred_own[r], idx, self.pf[r])
 
     def _strip_stage_b(self) -> None:
         """losses of every region on the assembled features (replicated), backward of this rank's rows through its window."""
         for r in range(self.R):
             self._losses(r, self._ns[r])
+        if self.deterministic:
+            for r in range(self.R):
+                mt, n = self._scatter_maps(r)
+                _ops.hypercol_scatter_plan(mt, self._idx[r][:n], self._plans[r])
         if self._halo is not None:
             # every rank back-propagates (gradient crosses the strip borders through the exchanges, and every sample's
             # taps that land in this window are scattered here); only the OWN rows of the pixel gradient are kept
-            if self.deterministic:
-                for r in range(self.R):
-                    _ops.hypercol_scatter_plan(self._mt_pred, self._idx[r][:self._ns[r]], self._plans[r])
             self.trunk.backward(self._scatter)
             self.gimg_full[:, :self.strips.own0].zero_()
             self.gimg_full[:, self.strips.own1:].zero_()
             return
-        mine = [r for r in range(self.R) if self._o1[r] > self._o0[r]]
-        if self.deterministic:
-            for r in mine:
-                _ops.hypercol_scatter_plan(self._mt_pred, self._idx[r][self._o0[r]:self._o1[r]], self._plans[r])
-        if mine:
-            self.trunk.backward(self._scatter, self._scatter_all)
-        else:
-            self.trunk.gimg.zero_()
+        self.trunk.backward(self._scatter, self._scatter_all)     # (a rank without samples back-propagates zeros)
         # rows outside the window still hold the previous step's all-reduced sum
         self.gimg_full[:, :self.strips.win0].zero_()
         self.gimg_full[:, self.strips.win1:].zero_()
@@ -347,8 +355,19 @@ class StepEngine:
 
     def step(self, indices: Sequence[torch.Tensor], strip_offsets: Optional[Sequence[int]] = None) -> None:
         if self.strips is not None:
-            self.forward_backward(indices, strip_offsets)
-            self.apply_gradients()
+            if self._strip_graphs is not None and all(int(i.shape[0]) == self._graph_n[r] for r, i in enumerate(indices)):
+                for dst, src in zip(self._graph_idx, indices):
+                    dst.copy_(src, non_blocking=True)
+                self._strip_inputs(self._graph_idx, strip_offsets)
+                ga, gb, gc = self._strip_graphs                       # graph | all-reduce | graph | all-reduce | graph
+                ga.replay()
+                parallel.allreduce_sum_(self._pf_all, self.group)
+                gb.replay()
+                parallel.allreduce_sum_(self.gimg_full, self.group)
+                gc.replay()
+            else:
+                self.forward_backward(indices, strip_offsets)
+                self.apply_gradients()
             self.steps_done += 1
             return
         if self._graph is not None and all(int(i.shape[0]) == self._graph_n[r] for r, i in enumerate(indices)):
@@ -363,7 +382,7 @@ class StepEngine:
             self.apply_gradients()
         self.steps_done += 1
 
-    def capture_graph(self, example_indices: Sequence[torch.Tensor]) -> None:
+    def capture_graph(self, example_indices: Sequence[torch.Tensor], example_offsets=None) -> None:
         """Capture forward_backward + apply_gradients into ONE hipGraph (the ~100 launches of a step
         replay as one submission; the 64-256 px scales are otherwise bound by host launch rate).  Index
         sets are copied into static buffers before each replay; a step whose index counts differ from
@@ -371,8 +390,13 @@ class StepEngine:
         variables / RMSprop slots are snapshotted around the warm-up and capture passes.
         Sharded regions (world > 1): the all-reduce stays outside -- TWO graphs, [fold .. pixel gradient] and
         [fold adjoint + RMSprop], with the collective launched between their replays.  Image strips run eagerly
-        (their per-step sample blocks change size)."""
+        (recompute margin; example_offsets = the block offsets of example_indices): THREE graphs, [fold .. gathers],
+        [losses .. pixel gradient of the window], [fold adjoint + RMSprop], the two all-reduces between their replays; the
+        block of samples a rank owns changes every step and is read from device memory (strotss_maps_t.sample_range).
+        Halo-exchange strips run eagerly (their trunk exchanges rows from Python after every layer)."""
         if self.strips is not None:
+            if self._halo is None and example_offsets is not None:
+                self._capture_strip_graphs(example_indices, example_offsets)
             return
         snap = [t.clone() for t in self.variables + self.rms]
         self._graph_idx = [i.clone() for i in example_indices]
@@ -403,6 +427,31 @@ class StepEngine:
         self._graph, self._graph_post = g, post
 
     # ------------------------------------------------------------------ read-outs (host sync)
+    def _capture_strip_graphs(self, example_indices, example_offsets) -> None:
+        snap = [t.clone() for t in self.variables + self.rms]
+        self._graph_idx = [i.clone() for i in example_indices]
+        self._graph_n = [int(i.shape[0]) for i in example_indices]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # one whole eager step first: workspaces, collectives, library state
+            self.forward_backward(self._graph_idx, example_offsets)
+            self.apply_gradients()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._strip_inputs(self._graph_idx, example_offsets)
+        torch.cuda.synchronize()
+        graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+        with _Capture(graphs[0], side):
+            self._strip_stage_a()
+        with _Capture(graphs[1], side):
+            self._strip_stage_b()
+        with _Capture(graphs[2], side):
+            self._fold_adjoint()
+            self.apply_gradients()
+        for t, s0 in zip(self.variables + self.rms, snap):
+            t.copy_(s0)
+        self._strip_graphs = tuple(graphs)
+
     def losses(self) -> dict:
         s = self.scalars.detach().cpu().numpy().astype(np.float64)
         lc = s[:, 0]

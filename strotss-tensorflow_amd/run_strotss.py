@@ -130,7 +130,7 @@ def _optimise_scale(eng, scl: int, content_masks, args, dev, quiet: bool = False
                 ev.record()
                 slots[(r, it % ring)] = (buf, ev)
             if it == 0 and not getattr(args, "no_graph", False):
-                eng.capture_graph(idx)
+                eng.capture_graph(idx, offsets)
             eng.step(idx, offsets)
             if step_trace is not None:
                 step_trace.append(eng.losses())

@@ -46,7 +46,9 @@ def main():
             eng.capture_graph(list(idx[0]))
         else:
             idx, offs = bench.strip_index_stream(S, 16, rng, dev, plan)
-            step = lambda i: eng.step([idx[i % 16]], offs[i % 16])
+            step = lambda i: eng.step(idx[i % 16], offs[i % 16])
+            if "graph" in sys.argv:            # the three stages as three graphs (eager otherwise)
+                eng.capture_graph(idx[0], offs[0])
             # stand-in for the feature all-reduce: the other ranks' rows come from the unsharded engine's matrix (left
             # zero they would tie every relaxed-EMD minimum and distort the loss kernels' time)
             parallel.allreduce_sum_ = (lambda e, ref: (lambda t, group=None: t.copy_(ref) if t is e._pf_all else t))(eng, ref_pf)
@@ -66,7 +68,7 @@ def main():
         if halo and plan is not None:
             print(f"    ({eng._halo.messages // 2 // 23} neighbour exchanges per step, stubbed) ", end="")
         print(f"world {world}: rank window {rows:4d} of {S} rows  {ms:6.2f} ms/step (no collectives, "
-              f"{'hipGraph' if plan is None else 'eager'})  -> compute-side speed-up bound {base / ms:4.2f}x")
+              f"{'hipGraph' if plan is None else ('3 hipGraphs' if eng._strip_graphs is not None else 'eager')})  -> compute-side speed-up bound {base / ms:4.2f}x")
         del eng
 
 

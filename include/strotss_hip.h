@@ -65,6 +65,12 @@ int strotss_fold_pyramid(const strotss_pyramid_t* pyr, float* img, void* stream)
  * gather form (no atomics).  Replaces the TF gradient of strotss_utils.py:162. */
 int strotss_resize_bilinear_adjoint(const float* gout, int oh, int ow, int c, float* gin, int ih,
                                     int iw, void* stream);
+/* The adjoint of the whole fold (3 channels): var[0] = the gradient of the folded image (input), var[k] for k >= 1 receive
+ * var[k] = resize^T(var[k-1]) -- the gradients of the pyramid levels (written through the const pointers of the
+ * descriptor).  Two levels per launch where each level halves the one above it to within a pixel (a workgroup recomputes
+ * the few middle-level rows its tile reads), strotss_resize_bilinear_adjoint level by level otherwise; bit for bit the
+ * same values either way. */
+int strotss_fold_pyramid_adjoint(const strotss_pyramid_t* gpyr, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * VGG16 trunk (frozen): nn/model.py:44-55 -- Keras Conv2D(3x3,'same',relu) / MaxPooling2D(2,2)

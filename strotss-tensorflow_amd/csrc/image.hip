@@ -129,6 +129,122 @@ __device__ __forceinline__ float adj_weight(int o, float scale, int in_size, int
   const AxisTap t = axis_tap(o, scale, in_size);
   return (t.lo == i ? 1.0f - t.lerp : 0.f) + (t.hi == i ? t.lerp : 0.f);
 }
+// one input pixel (iy, ix) of the adjoint, 3 channels, from any source of output rows: the summation order of
+// resize_adjoint_kernel (output rows ascending, columns ascending inside a row, zero weights skipped)
+struct AdjGlobal3 {
+  const float* p; int ow;
+  __device__ __forceinline__ const float* at(int oy, int ox) const { return p + ((size_t)oy * ow + ox) * 3; }
+};
+struct AdjRegion3 {                          // a rectangle of the output map staged in LDS
+  const float* p; int y0, x0, rw;
+  __device__ __forceinline__ const float* at(int oy, int ox) const { return p + ((oy - y0) * rw + (ox - x0)) * 3; }
+};
+__device__ __forceinline__ void adj_range(int i, float inv_scale, int out_size, int& o0, int& o1) {
+  // candidates: src(o) in (i-1, i+1)  <=>  o in ((i-0.5)/s - 0.5, (i+1.5)/s - 0.5); +-1 safety margin
+  o0 = max(0, (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 1);
+  o1 = min(out_size - 1, (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 1);
+}
+template <class Src>
+__device__ __forceinline__ void adjoint_pixel3(const Src& g, int oh, int ow, int ih, int iw, float sy, float sx, int iy,
+                                               int ix, float (&acc)[3]) {
+  int oy0, oy1, ox0, ox1;
+  adj_range(iy, 1.0f / sy, oh, oy0, oy1);
+  adj_range(ix, 1.0f / sx, ow, ox0, ox1);
+  acc[0] = acc[1] = acc[2] = 0.f;
+  if (ox1 - ox0 < ADJ_MAX) {                 // the column weights once per pixel (2x upsampling has <= 6 candidates)
+    float wx[ADJ_MAX];
+#pragma unroll
+    for (int q = 0; q < ADJ_MAX; ++q) wx[q] = (ox0 + q <= ox1) ? adj_weight(ox0 + q, sx, iw, ix) : 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      const float wy = adj_weight(oy, sy, ih, iy);
+      if (wy == 0.f) continue;
+      float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < ADJ_MAX; ++q)
+        if (wx[q] != 0.f) {
+          const float* p = g.at(oy, ox0 + q);
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) row[ch] += wx[q] * p[ch];
+        }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) acc[ch] += wy * row[ch];
+    }
+    return;
+  }
+  for (int oy = oy0; oy <= oy1; ++oy) {
+    const float wy = adj_weight(oy, sy, ih, iy);
+    if (wy == 0.f) continue;
+    float row[3] = {0.f, 0.f, 0.f};
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      const float w = adj_weight(ox, sx, iw, ix);
+      if (w != 0.f) {
+        const float* q = g.at(oy, ox);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) row[ch] += w * q[ch];
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) acc[ch] += wy * row[ch];
+  }
+}
+
+// TWO levels of the fold's adjoint in one launch (3 channels): g1 = up^T(g0), g2 = up^T(g1).  A workgroup owns an 8 x 8
+// tile of g2 and the 16 x 16 tile of g1 above it; it computes the g1 pixels of its tile plus the few rows and columns
+// around it that its g2 tile reads (recomputed, not exchanged), keeps them in LDS, stores its own, then gathers g2 from
+// LDS.  Every pixel runs adjoint_pixel3 -- the arithmetic of the level-by-level launches, bit for bit.
+#define ADJ2_T2 8
+#define ADJ2_REGION 32
+__global__ __launch_bounds__(256) void resize_adjoint_pair_kernel(const float* __restrict__ g0, int h0, int w0,
+                                                                  float* __restrict__ g1, int h1, int w1,
+                                                                  float* __restrict__ g2, int h2, int w2) {
+  __shared__ float mid[ADJ2_REGION * ADJ2_REGION * 3];
+  const int t = threadIdx.x;
+  const float sy1 = (float)h1 / (float)h0, sx1 = (float)w1 / (float)w0;      // level 1 from level 0
+  const float sy2 = (float)h2 / (float)h1, sx2 = (float)w2 / (float)w1;      // level 2 from level 1
+  // own tiles (either may be empty at the bottom / right edge)
+  const int ty0 = blockIdx.y * ADJ2_T2, ty1 = min(ty0 + ADJ2_T2, h2) - 1, tx0 = blockIdx.x * ADJ2_T2, tx1 = min(tx0 + ADJ2_T2, w2) - 1;
+  const int oy0 = blockIdx.y * 2 * ADJ2_T2, oy1 = min(oy0 + 2 * ADJ2_T2, h1) - 1;
+  const int ox0 = blockIdx.x * 2 * ADJ2_T2, ox1 = min(ox0 + 2 * ADJ2_T2, w1) - 1;
+  const bool has2 = ty0 <= ty1 && tx0 <= tx1, own1 = oy0 <= oy1 && ox0 <= ox1;
+  // region of level 1 to compute: own tile + what the level-2 tile gathers from
+  int ry0 = oy0, ry1 = oy1, rx0 = ox0, rx1 = ox1;
+  if (has2) {
+    int a, b, c, d;
+    adj_range(ty0, 1.0f / sy2, h1, a, b); adj_range(ty1, 1.0f / sy2, h1, c, d);
+    const int ny0 = a, ny1 = d;
+    adj_range(tx0, 1.0f / sx2, w1, a, b); adj_range(tx1, 1.0f / sx2, w1, c, d);
+    const int nx0 = a, nx1 = d;
+    if (own1) { ry0 = min(ry0, ny0); ry1 = max(ry1, ny1); rx0 = min(rx0, nx0); rx1 = max(rx1, nx1); }
+    else { ry0 = ny0; ry1 = ny1; rx0 = nx0; rx1 = nx1; }
+  } else if (!own1) {
+    return;
+  }
+  const int rh = ry1 - ry0 + 1, rw = rx1 - rx0 + 1;            // <= ADJ2_REGION (checked on the host)
+  const AdjGlobal3 src0{g0, w0};
+  for (int e = t; e < rh * rw; e += 256) {
+    const int ry = e / rw, rx = e - ry * rw;
+    const int iy = ry0 + ry, ix = rx0 + rx;
+    float acc[3];
+    adjoint_pixel3(src0, h0, w0, h1, w1, sy1, sx1, iy, ix, acc);
+    mid[e * 3 + 0] = acc[0]; mid[e * 3 + 1] = acc[1]; mid[e * 3 + 2] = acc[2];
+    if (own1 && iy >= oy0 && iy <= oy1 && ix >= ox0 && ix <= ox1) {
+      float* o = g1 + ((size_t)iy * w1 + ix) * 3;
+      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+  }
+  __syncthreads();
+  if (!has2) return;
+  const AdjRegion3 src1{mid, ry0, rx0, rw};
+  const int th = ty1 - ty0 + 1, tw = tx1 - tx0 + 1;
+  for (int e = t; e < th * tw; e += 256) {
+    const int iy = ty0 + e / tw, ix = tx0 + e % tw;
+    float acc[3];
+    adjoint_pixel3(src1, h1, w1, h2, w2, sy2, sx2, iy, ix, acc);
+    float* o = g2 + ((size_t)iy * w2 + ix) * 3;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+  }
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void resize_adjoint_kernel(const float* __restrict__ gout, int oh, int ow,
                                                              int c_rt, float* __restrict__ gin, int ih, int iw,
@@ -500,6 +616,34 @@ int strotss_fold_pyramid(const strotss_pyramid_t* pyr, float* img, void* stream)
   }
   hipLaunchKernelGGL(fold_pyramid_kernel, dim3((unsigned)cdiv(p.w[0], FOLD_TILE), (unsigned)cdiv(p.h[0], FOLD_TILE)), dim3(256),
                      0, (hipStream_t)stream, p, img);
+  ST_LAUNCH_RET();
+}
+
+// whether two adjoint levels fit one launch: each level halves the one above it to within a pixel (then an 8 x 8 tile's
+// footprint and the 16 x 16 tile above it span at most 28 rows / columns of the middle level)
+static bool adjoint_pair_ok(int a, int b) { return b >= 1 && a >= 2 * b - 1 && a <= 2 * b + 1; }
+
+int strotss_fold_pyramid_adjoint(const strotss_pyramid_t* g, void* stream) {
+  ST_CHECK_ARG(g && g->n_levels >= 2 && g->n_levels <= STROTSS_MAX_TENSORS, STROTSS_EINVAL);
+  for (int k = 0; k < g->n_levels; ++k) ST_CHECK_ARG(g->var[k] && g->h[k] > 0 && g->w[k] > 0, STROTSS_EINVAL);
+  int k = 0;
+  while (k + 1 < g->n_levels) {
+    const bool pair = k + 2 < g->n_levels && adjoint_pair_ok(g->h[k], g->h[k + 1]) && adjoint_pair_ok(g->w[k], g->w[k + 1]) &&
+                      adjoint_pair_ok(g->h[k + 1], g->h[k + 2]) && adjoint_pair_ok(g->w[k + 1], g->w[k + 2]);
+    if (pair) {
+      const unsigned gx = (unsigned)max(cdiv(g->w[k + 2], ADJ2_T2), cdiv(g->w[k + 1], 2 * ADJ2_T2));
+      const unsigned gy = (unsigned)max(cdiv(g->h[k + 2], ADJ2_T2), cdiv(g->h[k + 1], 2 * ADJ2_T2));
+      hipLaunchKernelGGL(resize_adjoint_pair_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)g->var[k], g->h[k], g->w[k], const_cast<float*>(g->var[k + 1]), g->h[k + 1], g->w[k + 1],
+                         const_cast<float*>(g->var[k + 2]), g->h[k + 2], g->w[k + 2]);
+      k += 2;
+    } else {
+      const int rc = strotss_resize_bilinear_adjoint(g->var[k], g->h[k], g->w[k], 3, const_cast<float*>(g->var[k + 1]),
+                                                     g->h[k + 1], g->w[k + 1], stream);
+      if (rc != 0) return rc;
+      k += 1;
+    }
+  }
   ST_LAUNCH_RET();
 }
 

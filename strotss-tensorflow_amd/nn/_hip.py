@@ -52,6 +52,7 @@ SIGNATURES = {
     "strotss_build_info": (C.c_char_p, []),
     "strotss_resize_bilinear": (_I, [_P, _I, _I, _I, _P, _I, _I, _F, _P, _P]),
     "strotss_fold_pyramid": (_I, [C.POINTER(PyramidT), _P, _P]),
+    "strotss_fold_pyramid_adjoint": (_I, [C.POINTER(PyramidT), _P]),
     "strotss_resize_bilinear_adjoint": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "strotss_conv3x3_c3_fwd": (_I, [_P, _I, _I, _P, _P, _I, C.POINTER(_F), C.POINTER(_F), _P, _P, _P]),
     "strotss_relu_bits_bytes": (_Z, [_I, _I, _I]),

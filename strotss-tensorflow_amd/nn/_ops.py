@@ -66,6 +66,21 @@ def fold_pyramid(variables: Sequence[torch.Tensor], out: torch.Tensor) -> Option
     return out
 
 
+def fold_pyramid_adjoint(gvars: Sequence[torch.Tensor]) -> bool:
+    """gvars[k] = resize_bilinear_adjoint(gvars[k-1]) for k >= 1 (gvars[0] = gradient of the folded image), two levels per
+    launch where the pyramid halves; False when the tensors are not a 3-channel pyramid of at most 8 levels (caller: level by
+    level)."""
+    if len(gvars) < 2 or len(gvars) > 8 or any(int(g.shape[-1]) != 3 for g in gvars):
+        return False
+    p = _hip.PyramidT()
+    p.n_levels = len(gvars)
+    for k, g in enumerate(gvars):
+        require(g, "pyramid gradient")
+        p.h[k], p.w[k], p.var[k] = int(g.shape[-3]), int(g.shape[-2]), g.data_ptr()
+    check(_hip.lib().strotss_fold_pyramid_adjoint(C.byref(p), stream_ptr()), "fold_pyramid_adjoint")
+    return True
+
+
 def resize_bilinear_adjoint(gout: torch.Tensor, ih: int, iw: int,
                             out: Optional[torch.Tensor] = None) -> torch.Tensor:
     require(gout, "resize adjoint input")

@@ -290,6 +290,8 @@ class StepEngine:
 
     def _fold_adjoint(self) -> None:
         """gvars[k] = up^T(gvars[k-1]): adjoint of the fold"""
+        if self._fold_one_launch is not False and _ops.fold_pyramid_adjoint(self.gvars):     # two levels per launch
+            return
         for k in range(1, len(self.variables)):
             hk, wk = self.sizes[k]
             _ops.resize_bilinear_adjoint(self.gvars[k - 1], hk, wk, out=self.gvars[k])

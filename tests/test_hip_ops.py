@@ -673,3 +673,26 @@ def test_fold_pyramid_one_launch_equals_level_by_level(ops, hw):
     assert np.abs(got.cpu().numpy() - ref).max() < 3e-6 * max(1.0, np.abs(ref).max())
     # a pyramid that does not shrink is refused (the caller then folds level by level)
     assert ops.fold_pyramid([pyr[-1], pyr[0]], torch.empty_like(pyr[-1])) is None or h * w == 1
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (170, 256), (683, 1024), (1024, 1024), (42, 64), (5, 7), (1, 1), (33, 2), (513, 97)])
+def test_fold_pyramid_adjoint_two_levels_per_launch_equals_level_by_level(ops, hw):
+    """strotss_fold_pyramid_adjoint (two adjoint levels per launch: a workgroup recomputes the middle-level pixels its tile
+    gathers from) against the chain of resize_bilinear_adjoint launches -- bit for bit -- and, as the adjoint of the fold,
+    <fold(p), g> == <p, fold^T(g)> in float64 on the host (strotss_utils.py:159-163 differentiated)."""
+    h, w = hw
+    gen = torch.Generator().manual_seed(h * 11 + w)
+    img = torch.rand(1, h, w, 3, generator=gen, dtype=torch.float64)
+    pyr64 = [p + 0.1 * torch.randn(p.shape, generator=gen, dtype=torch.float64) for p in O.make_laplacian_pyramid(img)]
+    sizes = [(int(p.shape[1]), int(p.shape[2])) for p in pyr64]
+    g0 = torch.randn(1, h, w, 3, generator=gen, dtype=torch.float64)
+    chain = [dev(g0)]
+    for hk, wk in sizes[1:]:
+        chain.append(ops.resize_bilinear_adjoint(chain[-1], hk, wk))
+    got = [dev(g0)] + [torch.full((1, hk, wk, 3), float("nan"), device="cuda") for hk, wk in sizes[1:]]
+    assert ops.fold_pyramid_adjoint(got)
+    for k, (a, b) in enumerate(zip(got, chain)):
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
+    lhs = float((O.fold_laplacian_pyramid(pyr64) * g0).sum())
+    rhs = sum(float((p * a.cpu().double()).sum()) for p, a in zip(pyr64, got))
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs)), (lhs, rhs)

@@ -41,6 +41,9 @@ __device__ long long fused_prof[2][64][8];
 #else
 #define MFMA_STEP(av, bv, cv) cv = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, cv, 0, 0, 0)
 #endif
+#ifndef FUSED_BT_SHARED
+#define FUSED_BT_SHARED 1          // 0: every output of B^T d as its own expression (the pre-round-3 form, for A/B builds)
+#endif
 #ifdef FUSED_NO_RAW
 #define ABL_R(x) do {} while (0)
 #else
@@ -153,15 +156,27 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
     auto ld = [&](int k, int q) { return *reinterpret_cast<const f32x2*>(src + (k * F_PW + q) * F_PS); };
     float* dst = V + (size_t)(18 * half) * (F_TILES * F_KC) + ttile * F_KC + ((((pr >> 1) ^ (ttile >> 3)) & 1) << 2) +
                  ((pr & 1) << 1);
+    // B^T d with the common subexpressions written out (the compiler may not reassociate floating point):
+    //   v1, v2 = (d4 - 4 d2) +- (d3 - 4 d1);   v3, v4 = (d4 - d2) +- 2 (d3 - d1):  12 packed operations instead of 16
     auto row_out = [&](int r, const f32x2 (&tr)[6]) {
       const f32x2 d0 = tr[0], d1 = tr[1], d2 = tr[2], d3 = tr[3], d4 = tr[4], d5 = tr[5];
       f32x2 v[6];
+#if FUSED_BT_SHARED
+      const f32x2 t0 = d4 - 4.f * d2, t1 = d3 - 4.f * d1, u0 = d4 - d2, u1 = d3 - d1;
+      v[0] = 4.f * d0 - 5.f * d2 + d4;
+      v[1] = t0 + t1;
+      v[2] = t0 - t1;
+      v[3] = u0 + 2.f * u1;
+      v[4] = u0 - 2.f * u1;
+      v[5] = 4.f * d1 - 5.f * d3 + d5;
+#else
       v[0] = 4.f * d0 - 5.f * d2 + d4;
       v[1] = -4.f * d1 - 4.f * d2 + d3 + d4;
       v[2] = 4.f * d1 - 4.f * d2 - d3 + d4;
       v[3] = -2.f * d1 - d2 + 2.f * d3 + d4;
       v[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
       v[5] = 4.f * d1 - 5.f * d3 + d5;
+#endif
 #pragma unroll
       for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x2*>(dst + (6 * r + q) * (F_TILES * F_KC)) = v[q];
     };
@@ -171,15 +186,27 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
       for (int q = 0; q < 6; ++q) {
         const f32x2 d0 = ld(0, q), d1 = ld(1, q), d2 = ld(2, q), d3 = ld(3, q), d4 = ld(4, q);
         ta[q] = 4.f * d0 - 5.f * d2 + d4;
+#if FUSED_BT_SHARED
+        const f32x2 t0 = d4 - 4.f * d2, t1 = d3 - 4.f * d1;
+        tb[q] = t0 + t1;
+        tc[q] = t0 - t1;
+#else
         tb[q] = -4.f * d1 - 4.f * d2 + d3 + d4;
         tc[q] = 4.f * d1 - 4.f * d2 - d3 + d4;
+#endif
       }
     } else {                                        // rows 3, 4, 5 from input rows 1..5
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const f32x2 d1 = ld(1, q), d2 = ld(2, q), d3 = ld(3, q), d4 = ld(4, q), d5 = ld(5, q);
+#if FUSED_BT_SHARED
+        const f32x2 u0 = d4 - d2, u1 = d3 - d1;
+        ta[q] = u0 + 2.f * u1;
+        tb[q] = u0 - 2.f * u1;
+#else
         ta[q] = -2.f * d1 - d2 + 2.f * d3 + d4;
         tb[q] = 2.f * d1 - d2 - 2.f * d3 + d4;
+#endif
         tc[q] = 4.f * d1 - 5.f * d3 + d5;
       }
     }

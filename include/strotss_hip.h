@@ -215,6 +215,12 @@ typedef struct {
  * strotss_utils.py:43-70, else truncating nearest (72-75).  idx: (n,2) float32 (row, col). */
 int strotss_hypercol_gather(const strotss_maps_t* maps, const float* idx, int n, int bilinear,
                             float* out, int ld, void* stream);
+/* strotss_hypercol_gather(maps_a, ..., out_a) and strotss_hypercol_gather(maps_b, ..., out_b) at the same n positions in ONE
+ * launch (the content and the prediction features of a train step, run_strotss.py:131-137), and, with zero != NULL, a zero
+ * fill of the zero_rows x ld matrix `zero` (the step's gradient rows).  maps_b may carry a sample_range. */
+int strotss_hypercol_gather2(const strotss_maps_t* maps_a, const strotss_maps_t* maps_b, const float* idx, int n,
+                             int bilinear, float* out_a, float* out_b, int ld, float* zero, int zero_rows,
+                             void* stream);
 /* Adjoint (bilinear only): gmap_k[pixel, c] += w * gfeat[s, off_k + c] * (relu_mask ? map_k>0 : 1)
  * for the maps k in [map_begin, map_end) only (the backward pass of the trunk needs the taps'
  * contributions one layer at a time); gmap[k] may be NULL outside that range.

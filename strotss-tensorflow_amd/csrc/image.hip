@@ -350,10 +350,8 @@ __device__ __forceinline__ SampleTap sample_tap(const strotss_maps_t& m, int k, 
 }
 
 // one block per sample row
-__global__ __launch_bounds__(256) void hypercol_gather_kernel(strotss_maps_t m, const float* __restrict__ idx,
-                                                              int bilinear, float* __restrict__ out, int ld,
-                                                              int dtotal) {
-  const int s = blockIdx.x;
+__device__ __forceinline__ void gather_row(const strotss_maps_t& m, const float* __restrict__ idx, int s, int bilinear,
+                                           float* __restrict__ out, int ld, int dtotal) {
   if (m.sample_range && (s < m.sample_range[0] || s >= m.sample_range[1])) return;      // not this rank's sample
   const float gx = idx[2 * s], gy = idx[2 * s + 1];
   float* o = out + (size_t)s * ld;
@@ -375,8 +373,30 @@ __global__ __launch_bounds__(256) void hypercol_gather_kernel(strotss_maps_t m, 
   }
   for (int ch = dtotal + threadIdx.x; ch < ld; ch += 256) o[ch] = 0.f;
 }
-
-// adjoint of the bilinear gather: float atomics, 256 contiguous bytes per wave instruction
+__global__ __launch_bounds__(256) void hypercol_gather_kernel(strotss_maps_t m, const float* __restrict__ idx,
+                                                              int bilinear, float* __restrict__ out, int ld,
+                                                              int dtotal) {
+  gather_row(m, idx, blockIdx.x, bilinear, out, ld, dtotal);
+}
+// two gathers at the same sample positions in one launch (blocks [0, n): maps a, [n, 2n): maps b) + an optional zero fill of
+// `zero_rows` rows of `zero` (block s of the first half clears row s, the last one also the rows from n on)
+__global__ __launch_bounds__(256) void hypercol_gather2_kernel(strotss_maps_t ma, strotss_maps_t mb,
+                                                               const float* __restrict__ idx, int n, int bilinear,
+                                                               float* __restrict__ out_a, float* __restrict__ out_b, int ld,
+                                                               int dtotal_a, int dtotal_b, float* __restrict__ zero,
+                                                               int zero_rows) {
+  const int b = blockIdx.x;
+  if (b < n) {
+    gather_row(ma, idx, b, bilinear, out_a, ld, dtotal_a);
+    if (zero) {
+      const int r1 = b == n - 1 ? zero_rows : min(b + 1, zero_rows);
+      for (int r = b; r < r1; ++r)
+        for (int ch = threadIdx.x; ch < ld; ch += 256) zero[(size_t)r * ld + ch] = 0.f;
+    }
+  } else {
+    gather_row(mb, idx, b - n, bilinear, out_b, ld, dtotal_b);
+  }
+}
 __global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m, const float* __restrict__ idx,
                                                                const float* __restrict__ gfeat, int ld,
                                                                int relu_mask_from, int map_begin,
@@ -671,6 +691,21 @@ int strotss_hypercol_gather(const strotss_maps_t* maps, const float* idx, int n,
   m.window_drop = 0;          // the gather ALWAYS clamps into the window; dropping is the scatter's (adjoint's) business
   hipLaunchKernelGGL(hypercol_gather_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, m, idx, bilinear,
                      out, ld, d);
+  ST_LAUNCH_RET();
+}
+
+int strotss_hypercol_gather2(const strotss_maps_t* maps_a, const strotss_maps_t* maps_b, const float* idx, int n,
+                             int bilinear, float* out_a, float* out_b, int ld, float* zero, int zero_rows, void* stream) {
+  ST_CHECK_ARG(maps_ok(maps_a) && maps_ok(maps_b) && idx && out_a && out_b && n > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(!zero || zero_rows > 0, STROTSS_EINVAL);
+  int da = 0, db = 0;
+  for (int k = 0; k < maps_a->n_maps; ++k) da += maps_a->c[k];
+  for (int k = 0; k < maps_b->n_maps; ++k) db += maps_b->c[k];
+  ST_CHECK_ARG(ld >= da && ld >= db, STROTSS_EINVAL);
+  strotss_maps_t a = *maps_a, b = *maps_b;
+  a.window_drop = b.window_drop = 0;        // the gather always clamps into the window (see strotss_hypercol_gather)
+  hipLaunchKernelGGL(hypercol_gather2_kernel, dim3(2 * n), dim3(256), 0, (hipStream_t)stream, a, b, idx, n, bilinear, out_a,
+                     out_b, ld, da, db, zero, zero_rows);
   ST_LAUNCH_RET();
 }
 

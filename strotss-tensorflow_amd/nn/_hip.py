@@ -73,6 +73,7 @@ SIGNATURES = {
     "strotss_maxpool2_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "strotss_maxpool2_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "strotss_hypercol_gather": (_I, [C.POINTER(MapsT), _P, _I, _I, _P, _I, _P]),
+    "strotss_hypercol_gather2": (_I, [C.POINTER(MapsT), C.POINTER(MapsT), _P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "strotss_hypercol_scatter": (_I, [C.POINTER(MapsT), _P, _I, _P, _I, _I, _I, _I, _P]),
     "strotss_hypercol_scatter_plan_bytes": (_Z, [_I]),
     "strotss_hypercol_scatter_plan": (_I, [C.POINTER(MapsT), _P, _I, _P, _Z, _P]),

@@ -208,13 +208,23 @@ class StepEngine:
         _hip.check(_hip.lib().strotss_hypercol_gather(_hip.C.byref(maps_t), idx.data_ptr(), n, 1, out.data_ptr(),
                                                       self.ld, _hip.stream_ptr()), "hypercol_gather")
 
-    def _losses(self, r: int, n: int):
-        """(alpha*loss_c + loss_s)/loss_denom/R and its gradient w.r.t. the sampled prediction."""
+    def _gather_both(self, maps_pred, idx, r: int) -> None:
+        """content rows, prediction rows and the zero fill of the gradient rows of region r in ONE launch"""
+        n = idx.shape[0]
+        _hip.check(_hip.lib().strotss_hypercol_gather2(_hip.C.byref(self._mt_content), _hip.C.byref(maps_pred), idx.data_ptr(), n,
+                                                       1, self.cf[r].data_ptr(), self.pf[r].data_ptr(), self.ld,
+                                                       self.gp[r].data_ptr(), int(self.gp[r].shape[0]), _hip.stream_ptr()),
+                   "hypercol_gather2")
+
+    def _losses(self, r: int, n: int, zeroed: bool = False):
+        """(alpha*loss_c + loss_s)/loss_denom/R and its gradient w.r.t. the sampled prediction.  zeroed: the gradient rows
+        were cleared by _gather_both already."""
         st = self.style_targets[r]
         pf, cf, gp, sc = self.pf[r], self.cf[r], self.gp[r], self.scalars[r]
         if n < pf.shape[0]:
             pf[n:].zero_(); cf[n:].zero_()
-        gp.zero_()
+        if not zeroed:
+            gp.zero_()
         base = 1.0 / (self.loss_denom * self.R)
         _ops.selfsim_fwd_bwd(pf, cf, n, self.d, self.alpha * base, gp, sc[0:])
         _ops.moment_fwd_bwd(st.mean, st.cov, pf, n, self.d, base, gp, sc[1:])
@@ -273,11 +283,10 @@ class StepEngine:
             n = int(idx.shape[0])
             assert 0 < n <= self.sample_size and idx.shape[1] == 2
             self._idx[r] = idx
-            self._gather(self._mt_content, idx, self.cf[r])
-            self._gather(self._mt_pred, idx, self.pf[r])
+            self._gather_both(self._mt_pred, idx, r)
             if self.deterministic:
                 _ops.hypercol_scatter_plan(self._mt_pred, idx, self._plans[r])
-            self._losses(r, n)
+            self._losses(r, n, zeroed=True)
         if self.my_regions:
             self.trunk.backward(self._scatter, self._scatter_all)
         else:
@@ -328,13 +337,12 @@ class StepEngine:
         self._pf_all.zero_()
         for r in range(self.R):
             idx = self._idx[r]
-            self._gather(self._mt_content, idx, self.cf[r])
-            self._gather(self._mt_pred_own[r], idx, self.pf[r])
+            self._gather_both(self._mt_pred_own[r], idx, r)
 
     def _strip_stage_b(self) -> None:
         """losses of every region on the assembled features (replicated), backward of this rank's rows through its window."""
         for r in range(self.R):
-            self._losses(r, self._ns[r])
+            self._losses(r, self._ns[r], zeroed=True)
         if self.deterministic:
             for r in range(self.R):
                 mt, n = self._scatter_maps(r)

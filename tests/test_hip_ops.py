@@ -328,6 +328,37 @@ def test_hypercol_gather_and_scatter(ops, hw):
         assert np.abs(a.cpu().numpy() - ref_g).max() < 1e-5 * max(1.0, np.abs(ref_g).max()), k
 
 
+def test_hypercol_two_gathers_and_the_zero_fill_in_one_launch(ops):
+    """strotss_hypercol_gather2 == two strotss_hypercol_gather calls at the same positions + a zero fill (the head of a train
+    step: content rows, prediction rows, cleared gradient rows), bit for bit; a device-side sample_range on the second set of
+    maps leaves the rows outside it untouched, as in the single gather (image strips)."""
+    from nn import _hip
+    h, w = 42, 64
+    rng = np.random.default_rng(8)
+    ma, mb = [dev(m) for m in _maps(h, w, 21)], [dev(m) for m in _maps(h, w, 22)]
+    idx = dev(O.make_indices(h, w, True, 200, rng))
+    n, d = int(idx.shape[0]), sum(int(m.shape[-1]) for m in ma)
+    ld, rows = ops.pad32(d), ops.pad32(n) + 32
+    divs = ops.map_divisors([ops.hwc(m)[:2] for m in ma])
+    ta, tb = _hip.make_maps(ma, divs), _hip.make_maps(mb, divs)
+    for rng_dev in (None, torch.tensor([37, 150], dtype=torch.int32, device="cuda")):
+        if rng_dev is not None:
+            tb.sample_range = rng_dev.data_ptr()
+        want_a = torch.full((rows, ld), 7.0, device="cuda"); want_b = torch.full((rows, ld), 7.0, device="cuda")
+        for t, o in ((ta, want_a), (tb, want_b)):
+            _hip.check(_hip.lib().strotss_hypercol_gather(_hip.C.byref(t), idx.data_ptr(), n, 1, o.data_ptr(), ld, _hip.stream_ptr()),
+                       "gather")
+        got_a = torch.full((rows, ld), 7.0, device="cuda"); got_b = torch.full((rows, ld), 7.0, device="cuda")
+        z = torch.full((rows, ld), 3.0, device="cuda")
+        _hip.check(_hip.lib().strotss_hypercol_gather2(_hip.C.byref(ta), _hip.C.byref(tb), idx.data_ptr(), n, 1, got_a.data_ptr(),
+                                                       got_b.data_ptr(), ld, z.data_ptr(), rows, _hip.stream_ptr()), "gather2")
+        torch.cuda.synchronize()
+        assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
+        assert float(z.abs().max()) == 0.0                     # every row, also those past the n samples
+        if rng_dev is not None:
+            assert float(got_b[:37].min()) == 7.0 and float(got_b[150:n].min()) == 7.0 and float(got_b[37:150, :d].max()) != 7.0
+
+
 @pytest.mark.parametrize("sorted_scatter", [False, True], ids=["atomic", "sorted"])
 def test_hypercol_scatter_window_drop(ops, sorted_scatter):
     """Windowed maps (spatially sharded trunk, `strotss_maps_t.row0/rows`): with `window_drop` the adjoint of ALL samples keeps

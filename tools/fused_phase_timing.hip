@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) {
     hipEventRecord(e0, 0);
-    int rc = st_winograd43_fused(in, hw, hw, cin, U, bias, cout, nullptr, 1, out, nullptr, nullptr, 0);
+    int rc = st_winograd43_fused(in, hw, hw, cin, U, bias, cout, nullptr, 1, out, nullptr, nullptr, nullptr, nullptr, 0);
     hipEventRecord(e1, 0); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("rc=%d  %.1f us\n", rc, ms * 1e3);

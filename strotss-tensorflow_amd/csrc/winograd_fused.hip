@@ -6,9 +6,9 @@
 // items of 4x8 Winograd tiles (16x32 output pixels) x 32 output channels and keeps everything on chip.  The input
 // channels stream through in chunks of 8, software-pipelined over the chunk stream of ALL the workgroup's items:
 //
-//   phase c:  [issue]  U fragments of chunk c+1 (L2 -> registers), input patch of chunk c+3 (HBM -> registers)
-//             waves 0-3: input transform of chunk c+1:  raw[(c+1)&1] (18x34 px x 8 ch)  ->  V[(c+1)&1] = B^T d B
+//   phase c:  waves 0-3: input transform of chunk c+1:  raw[(c+1)&1] (18x34 px x 8 ch)  ->  V[(c+1)&1] = B^T d B
 //             all waves: M[p] += V[c&1][p] U[p]^T for their 3 of the 36 positions (4 x v_mfma_f32_32x32x2_f32 each)
+//             all waves: [issue] U fragments of chunk c+1 (L2 -> registers), input patch of chunk c+3 (HBM -> registers)
 //             all waves: patch of chunk c+2 (in flight since phase c-1): registers -> raw[c&1]
 //             ONE barrier
 //
@@ -263,8 +263,6 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
       PROF(0);                                                                                                \
       CHUNK_AT(1, r1, k1) CHUNK_AT(3, r3, k3)                                                                 \
       const unsigned okm2 = (kc + 2 >= nchunk) ? nxt.okm : cur.okm;                                           \
-      load_u(r1.g, k1, BNEXT);                                                                                \
-      __builtin_amdgcn_sched_barrier(0);                                                                      \
       PROF(1);                                                                                                \
       const float* Vc = Vb + PAR * F_V + a_off;                                                               \
       f32x4 a[3];                                                                                             \
@@ -279,6 +277,9 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
       __builtin_amdgcn_sched_barrier(0);                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
       PROF(3);                                                                                                \
+      /* next chunk's U fragments: issued AFTER this wave's MFMAs -- at the phase start their address arithmetic   */ \
+      /* (64-bit scalar multiplies) and load issue kept every wave of the SIMD off the matrix pipe for ~250 cycles */ \
+      load_u(r1.g, k1, BNEXT);                                                                                \
       /* the patch loads (32 cache lines per wave instruction) go here, not to the phase start: 24 of them */ \
       /* queued in the CU's address unit right after the barrier stall every wave behind them             */ \
       ABL_R(load_raw(r3, k3, SLOAD));                                                                         \

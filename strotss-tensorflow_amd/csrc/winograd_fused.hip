@@ -77,6 +77,7 @@ __device__ __forceinline__ void bt6s(float (&d)[6]) {      // in-place B^T d (La
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct ItemRef { int goff[F_NLOAD]; unsigned okm; int g; };
 
@@ -303,11 +304,15 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
     const int region = item / NG;
     const int ry = region / RW, rx = region - ry * RW;
     const int y0 = ry * (4 * F_TR), x0 = rx * (4 * F_TC);
-    float Y[2][4][4];                               // starts at the bias (none for the data-gradient)
+    // Column arithmetic and stores: thread t < 512 owns tile t >> 4 and the TWO adjacent output channels 2 (t & 15), +1 --
+    // its LDS reads, mask / sign-word loads and stores are 8 bytes wide (half the instructions of one channel per thread
+    // and two tiles: the store issue, ~7 cycles per wave instruction, was the longest part of the epilogue)
+    const int etile = (t >> 4) & 31, ecp = t & 15;
+    float Y[2][4][4];                               // [channel of the pair]; starts at the bias (none for the data-gradient)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float bv = 0.f;
-      if constexpr (!MASK) { if (bias && t < 512) bv = bias[cur.g * 32 + (t & 31)]; }
+      if constexpr (!MASK) { if (bias && t < 512) bv = bias[cur.g * 32 + 2 * ecp + i]; }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -334,20 +339,19 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
       if (round == 0) PROF(1); else PROF(3);
       if (t < 512) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int e = t + 512 * i;
+        for (int k = 0; k < 3; ++k) {
+          const int q = 3 * round + k;
+          const float* src = colbuf[k] + etile * 32 + 2 * ecp;           // [row][tile][cout]: this thread's channel pair
+          f32x2 m[6];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int q = 3 * round + k;
-            const float* src = colbuf[k] + (e >> 5) * 32 + (e & 31);      // [row][tile][cout]
-            float m[6];
+          for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const f32x2*>(src + r * (F_TILES * 32));
 #pragma unroll
-            for (int r = 0; r < 6; ++r) m[r] = src[r * (F_TILES * 32)];
+          for (int i = 0; i < 2; ++i) {
             float sv[4];
-            sv[0] = m[0] + m[1] + m[2] + m[3] + m[4];
-            sv[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
-            sv[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
-            sv[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+            sv[0] = m[0][i] + m[1][i] + m[2][i] + m[3][i] + m[4][i];
+            sv[1] = m[1][i] - m[2][i] + 2.f * m[3][i] - 2.f * m[4][i];
+            sv[2] = m[1][i] + m[2][i] + 4.f * m[3][i] + 4.f * m[4][i];
+            sv[3] = m[1][i] - m[2][i] + 8.f * m[3][i] - 8.f * m[4][i] + m[5][i];
             // Y[r][:] += s[r] * A^T[:, q]
             constexpr float AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f},
                                         {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
@@ -364,73 +368,85 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
     }
     if (t < 512) {
       const float lo = (!MASK && relu) ? 0.f : -INFINITY;
+      const int ty = etile >> 3, tx = etile & 7;
+      const int co = cur.g * 32 + 2 * ecp;                   // even: every access below is 8-byte aligned (Cout is even)
+      const int yb = y0 + 4 * ty, xb = x0 + 4 * tx;
+      // Every memory-dependent value (bias: folded into Y before the rounds; ReLU mask: one batch of clamped
+      // loads condensed to a bit mask) is resolved before the first store, so the stores carry no s_waitcnt --
+      // with a load pending the compiler puts vmcnt(0) in front of each predicated store and they serialise.
+      const bool tile_in = yb < H && xb < W, full = yb + 3 < H && xb + 3 < W;
+      const size_t ob = tile_in ? ((size_t)yb * W + xb) * Cout + co : (size_t)co;
+      float* op = out + ob;
+      unsigned keep[2] = {0xffffu, 0xffffu};
+      // sign words of the tile grid (include/strotss_hip.h: relu_bits): one word per (tile, channel), byte r = row r
+      const size_t bo = ((size_t)(yb >> 2) * ((W + 3) >> 2) + (xb >> 2)) * Cout + co;
+      if (MASK && bits_in) {                       // 8 bytes instead of 2 x 16 activations
+        const u32x2 wv = *reinterpret_cast<const u32x2*>(bits_in + (tile_in ? bo : 0));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = t + 512 * i;
-        const int cl = e & 31, tile = e >> 5;
-        const int ty = tile >> 3, tx = tile & 7;
-        const int co = cur.g * 32 + cl;
-        const int yb = y0 + 4 * ty, xb = x0 + 4 * tx;
-        // Every memory-dependent value (bias: folded into Y before the rounds; ReLU mask: one batch of clamped
-        // loads condensed to a bit mask) is resolved before the first store, so the stores carry no s_waitcnt --
-        // with a load pending the compiler puts vmcnt(0) in front of each predicated store and they serialise.
-        const bool tile_in = yb < H && xb < W, full = yb + 3 < H && xb + 3 < W;
-        const size_t ob = tile_in ? ((size_t)yb * W + xb) * Cout + co : (size_t)co;
-        float* op = out + ob;
-        unsigned keep = 0xffffu;
-        // sign words of the tile grid (include/strotss_hip.h: relu_bits): one word per (tile, channel), byte r = row r
-        const size_t bo = ((size_t)(yb >> 2) * ((W + 3) >> 2) + (xb >> 2)) * Cout + co;
-        if (MASK && bits_in) {                       // 4 bytes instead of 16 activations
-          const unsigned wv = bits_in[tile_in ? bo : 0];
-          keep = (wv & 0xfu) | ((wv >> 4) & 0xf0u) | ((wv >> 8) & 0xf00u) | ((wv >> 12) & 0xf000u);
-        } else if constexpr (MASK) {
-          const float* mp = mask + ob;
-          float mk[4][4];
+        for (int i = 0; i < 2; ++i)
+          keep[i] = (wv[i] & 0xfu) | ((wv[i] >> 4) & 0xf0u) | ((wv[i] >> 8) & 0xf00u) | ((wv[i] >> 12) & 0xf000u);
+      } else if constexpr (MASK) {
+        const float* mp = mask + ob;
+        f32x2 mk[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const bool ok = tile_in && yb + r < H && xb + c < W;
+            mk[r][c] = *reinterpret_cast<const f32x2*>(mp + (ok ? (r * W + c) * Cout : 0));
+          }
+        keep[0] = keep[1] = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            keep[0] |= (mk[r][c][0] > 0.f ? 1u : 0u) << (4 * r + c);
+            keep[1] |= (mk[r][c][1] > 0.f ? 1u : 0u) << (4 * r + c);
+          }
+      }
+      auto outv = [&](int r, int c) {
+        f32x2 v;
+        v[0] = ((keep[0] >> (4 * r + c)) & 1u) ? fmaxf(Y[0][r][c], lo) : 0.f;
+        v[1] = ((keep[1] >> (4 * r + c)) & 1u) ? fmaxf(Y[1][r][c], lo) : 0.f;
+        return v;
+      };
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x2*>(op + (r * W + c) * Cout) = outv(r, c);
+      } else if (tile_in) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (yb + r < H && xb + c < W) *reinterpret_cast<f32x2*>(op + (r * W + c) * Cout) = outv(r, c);
+      }
+      if constexpr (!MASK) {
+        if (bits_out && tile_in) {
+          u32x2 wv = {0u, 0u};
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const bool ok = tile_in && yb + r < H && xb + c < W;
-              mk[r][c] = mp[ok ? (r * W + c) * Cout : 0];
+              wv[0] |= (Y[0][r][c] > 0.f ? 1u : 0u) << (8 * r + c);
+              wv[1] |= (Y[1][r][c] > 0.f ? 1u : 0u) << (8 * r + c);
             }
-          keep = 0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) keep |= (mk[r][c] > 0.f ? 1u : 0u) << (4 * r + c);
+          *reinterpret_cast<u32x2*>(bits_out + bo) = wv;
         }
-        if (full) {
+        // fused 2x2/2 max-pool of the activations just written (the tile's 4x4 outputs hold 2x2 windows);
+        // windows are emitted only where they lie inside the image (floor pooling)
+        if (pool) {
+          const int PH = H >> 1, PW = W >> 1, py0 = yb >> 1, px0 = xb >> 1;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+          for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-              op[(r * W + c) * Cout] = ((keep >> (4 * r + c)) & 1u) ? fmaxf(Y[i][r][c], lo) : 0.f;
-        } else if (tile_in) {
+            for (int pc = 0; pc < 2; ++pc)
+              if (py0 + pr < PH && px0 + pc < PW) {
+                f32x2 pv;
+                unsigned short code2 = 0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (yb + r < H && xb + c < W)
-                op[(r * W + c) * Cout] = ((keep >> (4 * r + c)) & 1u) ? fmaxf(Y[i][r][c], lo) : 0.f;
-        }
-        if constexpr (!MASK) {
-          if (bits_out && tile_in) {
-            unsigned wv = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int c = 0; c < 4; ++c) wv |= (Y[i][r][c] > 0.f ? 1u : 0u) << (8 * r + c);
-            bits_out[bo] = wv;
-          }
-          // fused 2x2/2 max-pool of the activations just written (the tile's 4x4 outputs hold 2x2 windows);
-          // windows are emitted only where they lie inside the image (floor pooling)
-          if (pool) {
-            const int PH = H >> 1, PW = W >> 1, py0 = yb >> 1, px0 = xb >> 1;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-              for (int pc = 0; pc < 2; ++pc)
-                if (py0 + pr < PH && px0 + pc < PW) {
+                for (int i = 0; i < 2; ++i) {
                   const float v4[4] = {Y[i][2 * pr][2 * pc], Y[i][2 * pr][2 * pc + 1], Y[i][2 * pr + 1][2 * pc],
                                        Y[i][2 * pr + 1][2 * pc + 1]};
                   int best = 0;
@@ -438,11 +454,13 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
 #pragma unroll
                   for (int q4 = 1; q4 < 4; ++q4)
                     if (v4[q4] > bv) { bv = v4[q4]; best = q4; }
-                  const size_t po = ((size_t)(py0 + pr) * PW + px0 + pc) * Cout + co;
-                  pool[po] = fmaxf(bv, lo);
-                  if (pool_code) pool_code[po] = (unsigned char)(bv > 0.f ? best : 4);   // argmax code of maxpool2_fwd
+                  pv[i] = fmaxf(bv, lo);
+                  code2 |= (unsigned short)((bv > 0.f ? best : 4) << (8 * i));   // argmax code of maxpool2_fwd
                 }
-          }
+                const size_t po = ((size_t)(py0 + pr) * PW + px0 + pc) * Cout + co;
+                *reinterpret_cast<f32x2*>(pool + po) = pv;
+                if (pool_code) *reinterpret_cast<unsigned short*>(pool_code + po) = code2;
+              }
         }
       }
     }

@@ -278,3 +278,29 @@ def test_sinkhorn_fullsize_permutation_invariance_and_bounds():
     rel = float((ya.grad[perm] - yb.grad).norm() / yb.grad.norm())
     assert rel < 1e-3, rel
     assert float(ca) >= float(L.relaxed_emd(x, y)) - 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(1024, 64, 64), (512, 128, 128), (256, 256, 256), (128, 512, 512)])
+def test_relu_sign_words_fullsize(cfg):
+    """Sign words at the VGG16 shapes of a 1024-px image, whichever kernel the route ends in: the words a forward pass writes
+    from its registers == the words derived from the activation it wrote (every tile, every channel), and the data-gradient
+    masked by them == the data-gradient masked by the activation, bit for bit (include/strotss_hip.h: strotss_relu_bits)."""
+    from nn import _ops
+    hw, cin, cout = cfg
+    g = torch.Generator().manual_seed(hw * 3 + cin)
+    wt = torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    x = _rand(1, hw, hw, cin, seed=7, relu=True)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    u_f = _ops.winograd_weights(wt.permute(3, 2, 0, 1).contiguous().to(DEV), 4, DEV)
+    bits = _ops.relu_bits_buffer(hw, hw, cout, DEV)
+    act = _ops.conv3x3_winograd_fwd(x, u_f, bias, relu_bits_out=bits)
+    assert torch.equal(bits, _ops.relu_bits(act))                      # hw % 4 == 0: no unspecified bits
+    frac = float((act > 0).float().mean())
+    assert 0.2 < frac < 0.8, frac                                       # (the pattern is not trivial)
+    # the NEXT layer's data-gradient: gradient (hw, hw, cout2) back to this activation, masked by its sign
+    u_b = _ops.winograd_weights(wt.flip(0, 1).permute(2, 3, 0, 1).contiguous().to(DEV), 4, DEV)   # (cin, cout) kernel: cout -> cin
+    gy = _rand(1, hw, hw, cout, seed=8)
+    xbits = _ops.relu_bits(x)
+    a = _ops.conv3x3_winograd_dgrad(gy, u_b, cin, act_in=x)
+    b = _ops.conv3x3_winograd_dgrad(gy, u_b, cin, relu_bits=xbits)
+    assert torch.equal(a, b)

@@ -285,6 +285,18 @@ size_t strotss_remd_workspace_bytes(int ns, int n, int ld);
 int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n,
                              int d, int ld, float gscale, float* gpred, float* loss_out,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* The same with its prologue already done (a train step computes the prediction rows' reciprocal norms and x3 panels for
+ * the content loss anyway, and the style rows' panels do not change within a scale): pred_inv_norm / pred_panels as
+ * strotss_row_inv_norm_x3(pred) writes them -- e.g. the ones strotss_selfsim_fwd_bwd left in ITS workspace
+ * (strotss_selfsim_pred_panels: pointers into that workspace, valid until it is reused; *panels == NULL when the cost
+ * matrices run on the f32 MFMA, STROTSS_X3=0) -- and style_panels = strotss_row_inv_norm_x3(style).  Same result bit for
+ * bit, one launch and two passes over the rows less. */
+int strotss_selfsim_pred_panels(void* workspace, size_t workspace_bytes, int n, int ld, const float** inv_norm,
+                                const void** panels);
+int strotss_remd_cos_fwd_bwd_panels(const float* style, const float* rs, const void* style_panels, int ns,
+                                    const float* pred, const float* pred_inv_norm, const void* pred_panels, int n,
+                                    int d, int ld, float gscale, float* gpred, float* loss_out, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 /* loss_out[0] = relaxed_emd(yuv(style[:, :3]), yuv(pred[:, :3]), 'both') (run_strotss.py:37-39);
  * gpred[:, :3] += gscale*dloss/dpred[:, :3].  style/pred are the full (rows, ld) matrices, of
  * which only the first three columns are read.  rgb_to_yuv != 0 applies convert_rgb_to_yuv

@@ -1020,6 +1020,26 @@ size_t strotss_remd_workspace_bytes(int ns, int n, int ld) {
   return w.off;
 }
 
+// cosine REMD after its prologue: rp / xp = reciprocal norms / x3 panels of pred, xs = x3 panels of style (NULL panels: the
+// cost matrix on the f32 MFMA from the rows themselves)
+static int remd_cos_core(const float* style, const float* rs, const __bf16* xs, int ns, const float* pred, const float* rp,
+                         const __bf16* xp, int n, int ld, float gscale, float* gpred, float* loss_out, RemdWs& s,
+                         hipStream_t st) {
+  // pred-major cost matrix Ct[j][i] (bitwise the transpose of cosine_distance(style, pred): same products, same k
+  // order), so that the backward kernel's scans of "column j" are contiguous: minima over i per prediction row j
+  // are row minima (cmin), minima over j per style row i column minima (rmin)
+  const int ldt = s.ldt;
+  if (xp && xs) CHK(st_cosine_distance_x3(xp, rp, n, xs, rs, ns, ld, 0, s.C, ldt, 1, 0, 0, 0, st));
+  else CHK(st_cosine_distance(pred, rp, n, style, rs, ns, ld, s.C, ldt, st));
+  hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.cmin,
+                     s.ccnt, s.pmin, s.pcnt);
+  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin, s.rcnt,
+                     s.cmin, n, 1, loss_out, s.sel);
+  hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldt, style, rs, ns, pred, rp, n,
+                     ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
+  ST_LAUNCH_RET();
+}
+
 int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n, int d,
                              int ld, float gscale, float* gpred, float* loss_out, void* workspace,
                              size_t workspace_bytes, void* stream) {
@@ -1039,19 +1059,33 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
     hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
   }
   LAUNCH_OK();
-  // pred-major cost matrix Ct[j][i] (bitwise the transpose of cosine_distance(style, pred): same products, same k
-  // order), so that the backward kernel's scans of "column j" are contiguous: minima over i per prediction row j
-  // are row minima (cmin), minima over j per style row i column minima (rmin)
-  const int ldt = s.ldt;
-  if (x3) CHK(st_cosine_distance_x3(s.xp, s.rp, n, s.xs, rs, ns, ld, 0, s.C, ldt, 1, 0, 0, 0, st));
-  else CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.C, ldt, st));
-  hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.cmin,
-                     s.ccnt, s.pmin, s.pcnt);
-  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin, s.rcnt,
-                     s.cmin, n, 1, loss_out, s.sel);
-  hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldt, style, rs, ns, pred, s.rp, n,
-                     ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
-  ST_LAUNCH_RET();
+  return remd_cos_core(style, rs, x3 ? s.xs : nullptr, ns, pred, s.rp, x3 ? s.xp : nullptr, n, ld, gscale, gpred, loss_out, s,
+                       st);
+}
+
+int strotss_selfsim_pred_panels(void* workspace, size_t workspace_bytes, int n, int ld, const float** inv_norm,
+                                const void** panels) {
+  ST_CHECK_ARG(workspace && inv_norm && panels && n > 0 && ld > 0 && ld % 32 == 0, STROTSS_EINVAL);
+  Workspace w(workspace, workspace_bytes);
+  SelfsimWs s;
+  ST_CHECK_ARG(s.plan(w, n, ld), STROTSS_EINVAL);
+  *inv_norm = s.rp;
+  *panels = cost_x3() ? (const void*)s.xp : nullptr;
+  return 0;
+}
+
+int strotss_remd_cos_fwd_bwd_panels(const float* style, const float* rs, const void* style_panels, int ns, const float* pred,
+                                    const float* pred_inv_norm, const void* pred_panels, int n, int d, int ld, float gscale,
+                                    float* gpred, float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(style && rs && style_panels && pred && pred_inv_norm && pred_panels && gpred && loss_out && workspace &&
+               ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(ns <= REMD_MAX_LIST, STROTSS_ERANGE);
+  Workspace w(workspace, workspace_bytes);
+  RemdWs s;
+  ST_CHECK_ARG(s.plan(w, ns, n, ld), STROTSS_EINVAL);
+  return remd_cos_core(style, rs, (const __bf16*)style_panels, ns, pred, pred_inv_norm, (const __bf16*)pred_panels, n, ld,
+                       gscale, gpred, loss_out, s, (hipStream_t)stream);
 }
 
 size_t strotss_remd_metric_workspace_bytes(int ns, int n) {

@@ -449,6 +449,26 @@ def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out):
                                      ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "remd_cos_fwd_bwd")
 
 
+def remd_cos_fwd_bwd_after_selfsim(style, rs, style_panels, ns, pred, n, d, gscale, gpred, loss_out):
+    """remd_cos_fwd_bwd for the prediction rows that selfsim_fwd_bwd has just processed (nothing else may have used the
+    "selfsim" workspace since): their reciprocal norms and x3 panels are taken from that workspace, the style rows' panels
+    from `style_panels` (row_inv_norm_x3(style)[1], constant within a scale) -- bit for bit remd_cos_fwd_bwd, one launch and
+    two passes over the rows less.  style_panels None or the cost matrices on the f32 MFMA: the plain call."""
+    l = _hip.lib()
+    ld = pred.shape[1]
+    nb = l.strotss_selfsim_workspace_bytes(n, ld)
+    ws = workspaces.get("selfsim", nb, pred.device)
+    rp, xp = C.c_void_p(), C.c_void_p()
+    check(l.strotss_selfsim_pred_panels(ptr(ws), nb, n, ld, C.byref(rp), C.byref(xp)), "selfsim_pred_panels")
+    if style_panels is None or not xp.value:
+        return remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out)
+    nbr = l.strotss_remd_workspace_bytes(ns, n, ld)
+    wsr = workspaces.get("remd", nbr, pred.device)
+    check(l.strotss_remd_cos_fwd_bwd_panels(ptr(style), ptr(rs), ptr(style_panels), ns, ptr(pred), rp.value, xp.value, n, d, ld,
+                                            gscale, ptr(gpred), ptr(loss_out), ptr(wsr), nbr, stream_ptr()),
+          "remd_cos_fwd_bwd_panels")
+
+
 def sinkhorn_cos_fwd_bwd(style, rs, ns, pred, n, d, l, n_iter, gscale, gpred, loss_out):
     lib = _hip.lib()
     nb = lib.strotss_sinkhorn_workspace_bytes(ns, n, n_iter)

@@ -31,12 +31,14 @@ class StyleTarget:
     inv_norm: torch.Tensor   # row_inv_norm(feats)
     mean: torch.Tensor       # (ld,)
     cov: torch.Tensor        # (ld, ld)
+    panels: Optional[torch.Tensor] = None   # the rows as x3 panels (bf16x3 GEMM operand of the relaxed EMD), made once
 
     @staticmethod
     def build(feats: torch.Tensor, ns: int, d: int) -> "StyleTarget":
         rs = _ops.row_inv_norm(feats, ns)
         mean, cov = _ops.moment_stats(feats, ns, d)
-        return StyleTarget(feats, ns, rs, mean, cov)
+        panels = _ops.row_inv_norm_x3(feats, ns)[1] if int(feats.shape[1]) % 32 == 0 else None
+        return StyleTarget(feats, ns, rs, mean, cov, panels)
 
 
 def extract_features(params: VGGParams, image: torch.Tensor) -> List[torch.Tensor]:
@@ -228,7 +230,9 @@ class StepEngine:
         base = 1.0 / (self.loss_denom * self.R)
         _ops.selfsim_fwd_bwd(pf, cf, n, self.d, self.alpha * base, gp, sc[0:])
         _ops.moment_fwd_bwd(st.mean, st.cov, pf, n, self.d, base, gp, sc[1:])
-        _ops.remd_cos_fwd_bwd(st.feats, st.inv_norm, st.ns, pf, n, self.d, base, gp, sc[2:])
+        # the relaxed EMD borrows the prediction rows' norms and x3 panels from the content loss's workspace (the moment
+        # term has its own) and the style rows' panels from the StyleTarget
+        _ops.remd_cos_fwd_bwd_after_selfsim(st.feats, st.inv_norm, st.panels, st.ns, pf, n, self.d, base, gp, sc[2:])
         _ops.palette_remd_fwd_bwd(st.feats, st.ns, pf, n, self.inv_alpha * base, gp, sc[3:])
 
     def _scatter_maps(self, r: int):

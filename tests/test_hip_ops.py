@@ -584,6 +584,31 @@ def test_loss_gradients_accumulate(ops):
     assert abs(lv[0] - lc) < 1e-5 and abs(lv[1] + lv[2] + lv[3] / 16.0 - ls) < 1e-5
 
 
+@pytest.mark.parametrize("n,ns,d", [(64, 64, 67), (1024, 1024, 2179), (200, 333, 131)])
+def test_remd_with_borrowed_panels_equals_the_plain_call_bitwise(ops, n, ns, d):
+    """strotss_remd_cos_fwd_bwd_panels (prediction rows' norms and x3 panels borrowed from the content loss's workspace,
+    style panels made once) == strotss_remd_cos_fwd_bwd: losses and gradient rows bit for bit, with the moment term run in
+    between (it has its own workspace and must not disturb the borrowed panels)."""
+    x = _feat(ns, d, 26); y = _feat(n, d, 27); c = _feat(n, d, 28)
+    bx, by, bc = _fbuf(ops, x), _fbuf(ops, y), _fbuf(ops, c)
+    mean, cov = ops.moment_stats(bx, ns, d)
+    rs = ops.row_inv_norm(bx, ns)
+    panels = ops.row_inv_norm_x3(bx, ns)[1]
+    outs = []
+    for shared in (False, True):
+        g = torch.zeros_like(by); l = torch.zeros(4, device="cuda")
+        ops.selfsim_fwd_bwd(by, bc, n, d, 0.7, g, l[0:])
+        ops.moment_fwd_bwd(mean, cov, by, n, d, 0.3, g, l[1:])
+        if shared:
+            ops.remd_cos_fwd_bwd_after_selfsim(bx, rs, panels, ns, by, n, d, 0.9, g, l[2:])
+        else:
+            ops.remd_cos_fwd_bwd(bx, rs, ns, by, n, d, 0.9, g, l[2:])
+        torch.cuda.synchronize()
+        outs.append((g, l))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    assert float(outs[0][1][2]) != 0.0
+
+
 def test_l2_distance_and_winograd_weight_transform(ops):
     """nn/losses.py:18-24 on the f32 MFMA (any width; the reference uses width 3), and the Winograd weight transform
     G g G^T in float64 on the device -- the package holds no library GEMM (torch matmul / einsum) any more."""

@@ -592,16 +592,33 @@ __global__ __launch_bounds__(256) void center_kernel(const float* __restrict__ y
 // mean == NULL: no centring; Pc == NULL: transposed panels only (the self-similarity backward's B operand).
 __global__ __launch_bounds__(256) void center_x3_kernel(const float* __restrict__ y, int n, int npad, int ld,
                                                         const float* __restrict__ mean, __bf16* __restrict__ Pc,
-                                                        __bf16* __restrict__ Pt) {
+                                                        __bf16* __restrict__ Pt, const float* __restrict__ psum = nullptr,
+                                                        float* __restrict__ mean_out = nullptr) {
+  // psum != NULL: the column means come from col_sum_partial_kernel's partial sums here (the arithmetic of
+  // col_mean_final_kernel, chunk order and division included -- one launch less), block row 0 also stores them
   __shared__ float tile[32][33];
+  __shared__ __attribute__((aligned(16))) float smean[32];
   const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  if (psum) {
+    if (threadIdx.x < 32) {
+      const int col = j0 + threadIdx.x;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < COL_CHUNKS; ++k) a += psum[(size_t)k * ld + col];
+      a = a / (float)n;
+      smean[threadIdx.x] = a;
+      if (mean_out && blockIdx.y == 0) mean_out[col] = a;
+    }
+    __syncthreads();
+  }
   {
     const int il = threadIdx.x >> 3, j4 = threadIdx.x & 7;
     const int i = i0 + il, j = j0 + 4 * j4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (i < n) {
       v = *reinterpret_cast<const f32x4*>(y + (size_t)i * ld + j);
-      if (mean) v = v - *reinterpret_cast<const f32x4*>(mean + j);
+      if (psum) v = v - *reinterpret_cast<const f32x4*>(smean + 4 * j4);
+      else if (mean) v = v - *reinterpret_cast<const f32x4*>(mean + j);
       if (Pc) x3_store4(Pc, n, i, j, v);
     }
     tile[il][4 * j4 + 0] = v[0]; tile[il][4 * j4 + 1] = v[1]; tile[il][4 * j4 + 2] = v[2]; tile[il][4 * j4 + 3] = v[3];
@@ -1160,13 +1177,13 @@ int strotss_moment_stats(const float* x, int n, int d, int ld, float* mean_out, 
   ST_CHECK_ARG(s.plan(w, n, ld), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(ld, 64), COL_CHUNKS), dim3(256), 0, st, x, n, ld, s.psum);
-  hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, st, s.psum, n, ld, mean_out);
   if (moment_x3()) {      // same GEMM core as the prediction side (strotss_moment_fwd_bwd): identical statistics, bit for bit
     hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, s.rows / 32), dim3(256), 0, st, x, n, s.rows, ld,
-                       (const float*)mean_out, (__bf16*)nullptr, s.Pt);
+                       (const float*)nullptr, (__bf16*)nullptr, s.Pt, (const float*)s.psum, mean_out);   // (means: in here)
     LAUNCH_OK();
     return st_gram_tn_x3(s.Pt, s.rows, ld, 1.0f / (float)n, cov_out, st);
   }
+  hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, st, s.psum, n, ld, mean_out);
   hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st, x,
                      n, s.rows, ld, mean_out, s.cy);
   LAUNCH_OK();
@@ -1184,15 +1201,15 @@ int strotss_moment_fwd_bwd(const float* style_mean, const float* style_cov, cons
   ST_CHECK_ARG(s.plan(w, n, ld), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(ld, 64), COL_CHUNKS), dim3(256), 0, st, pred, n, ld, s.psum);
-  hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, st, s.psum, n, ld, s.mean);
   const bool x3 = moment_x3();
   int n_partial = 0;
-  if (x3) {           // both GEMMs on the bf16x3 core (csrc/mfma_x3.h)
-    hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, s.rows / 32), dim3(256), 0, st, pred, n, s.rows, ld, s.mean, s.Pc,
-                       s.Pt);
+  if (x3) {           // both GEMMs on the bf16x3 core (csrc/mfma_x3.h); the column means are finished inside the centring
+    hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, s.rows / 32), dim3(256), 0, st, pred, n, s.rows, ld,
+                       (const float*)nullptr, s.Pc, s.Pt, (const float*)s.psum, s.mean);
     LAUNCH_OK();
     CHK(st_moment_fwd_x3(s.Pt, s.rows, ld, style_cov, s.Tp, 1.0f / (float)n, s.partial, &n_partial, st));
   } else {
+    hipLaunchKernelGGL(col_mean_final_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, st, s.psum, n, ld, s.mean);
     hipLaunchKernelGGL(center_kernel, dim3(min(2048, cdiv((size_t)s.rows * ld / 4, 256))), dim3(256), 0, st,
                        pred, n, s.rows, ld, s.mean, s.cy);
     LAUNCH_OK();

@@ -671,6 +671,23 @@ def test_fused_winograd_kernel_on_every_shape():
     assert " passed" in out.stdout
 
 
+def test_losses_and_convs_with_the_bf16x3_core_switched_off():
+    """STROTSS_X3=0 keeps every GEMM on the f32 MFMA (cost matrices, covariance, Winograd GEMMs): the fallback branches of
+    the loss entry points (separate column-mean launch, plain relaxed-EMD prologue, no borrowed panels) and of the conv
+    routing must pass the same parity tests.  Read once per process: a child process."""
+    import os, subprocess, sys
+    if os.environ.get("STROTSS_X3") == "0":
+        pytest.skip("already inside the forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STROTSS_X3="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_ops.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "losses_fwd_bwd or loss_gradients_accumulate or borrowed_panels or remd_and_palette_ties or "
+                                "test_conv_winograd_fwd_and_dgrad or cosine_distance"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
 def test_gemm_out_winograd_kernel_on_every_shape():
     """The two-kernel F(4x4,3x3) form (csrc/winograd_gemm_out.hip: the 36 bf16x3 GEMMs with the output transform folded
     in) is chosen for layers with at least 192 work items; force it on every shape it accepts (cin % 32 == 0,

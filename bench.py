@@ -204,8 +204,6 @@ ROUTE_NAMES = {0: "F(2x2,3x3): winograd_in_kernel -> gemm_kc_pipe_kernel x16 (f3
                2: "winograd43_in_kernel -> gemm_kc_pipe_kernel x36 (f32 MFMA) -> winograd43_out_kernel",
                3: "winograd43_in_x3_kernel -> gemm_x3_kernel<X3CfgK16<3>> x36 (bf16x3, 128x128 tiles) -> winograd43_out_kernel",
                4: "winograd43_in_x3_kernel -> gemm_x3_kernel<X3Cfg<64>> x36 (bf16x3, 64x64 tiles) -> winograd43_out_kernel",
-               5: "winograd43_in_x3_kernel -> gemm_x3_stream_kernel (bf16x3, persistent) -> winograd43_out_kernel",
-               6: "winograd43_in_x3_kernel -> winograd43_gemm_out_kernel (bf16x3 GEMMs + output transform)",
                -1: "conv3x3_mfma_pipe_kernel / conv3x3_mfma_splitk_kernel (direct 3x3, f32 MFMA)"}
 
 

@@ -170,8 +170,6 @@ int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, co
 #define STROTSS_ROUTE_F4_GEMM_F32 2     /* F(4x4,3x3), three kernels, 36 f32-MFMA GEMMs                                 */
 #define STROTSS_ROUTE_F4_X3_GEMM_128 3  /* three kernels, 36 bf16x3 GEMMs, 128 x 128 tiles (K16 ring, two workgroups/CU)*/
 #define STROTSS_ROUTE_F4_X3_GEMM_64 4   /* the same on 64 x 64 tiles                                                    */
-#define STROTSS_ROUTE_F4_X3_STREAM 5    /* three kernels, the bf16x3 GEMMs as one persistent stream (mfma_x3_stream.h)  */
-#define STROTSS_ROUTE_F4_X3_GEMM_OUT 6  /* two kernels: input transform + GEMMs with the output transform folded in     */
 int strotss_conv3x3_winograd_route(int h, int w, int cin, int cout, int tile_m, int has_packed, int has_x3);
 /* MEASUREMENT HOOK, process-wide and not thread-safe: which stages of the F(4x4,3x3) three-kernel form are launched
  * from now on (bit 0 input transform, bit 1 GEMMs, bit 2 output transform; 7 = all, the default); returns the previous

@@ -5,7 +5,6 @@
 #include "internal.h"
 #include "mfma_pipe.h"
 #include "mfma_x3.h"
-#include "mfma_x3_stream.h"
 
 namespace {
 
@@ -427,49 +426,6 @@ struct X3Mirror {       // writes the transpose of the workgroup's tile through 
     });
   }
 };
-
-// The same products as a STREAM (mfma_x3_stream.h): one persistent workgroup per CU walks the 128 x 128 tiles of the
-// whole batch with one continuous pipeline.  Needs N % 128 == 0, K in {128, 256, 512} and C rows padded to a multiple of
-// 128 per batch entry (strideC >= round_up(M, 128) * ldc): every store is unconditional.  Returns 1 when the shape does
-// not qualify (the caller takes the per-tile form).
-bool st_gemm_x3_stream_ok(int M, int N, int K, int batch) {
-  // default OFF: measured on block3 / block4 at 1024 px the stream takes 138 us against the per-tile form's 125 us -- its
-  // 151 MB of result stores share the in-order vmcnt with the LDS-DMA and the layer is HBM-bound either way (without its
-  // stores the same kernel runs in 82 us).  STROTSS_X3_STREAM=1: where a layer has >= 512 tiles; 2: everywhere.
-  static const int on = [] { const char* v = getenv("STROTSS_X3_STREAM"); return v ? atoi(v) : 0; }();
-  if (!on || N % 128 != 0 || !(K == 128 || K == 256 || K == 512)) return false;
-  const long long tiles = (long long)cdiv(M, 128) * (N / 128) * batch;
-  // fewer than two tiles per CU: the list is too short to keep 256 pipelines full (block5 at 1024 px: 288 tiles)
-  static const long long min_tiles = [] { const char* v = getenv("STROTSS_X3_STREAM_MIN_TILES"); return v ? atoll(v) : 512ll; }();
-  return on == 2 || tiles >= min_tiles;
-}
-static int stream_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount / 8 * 8 : 256;
-    if (cus < 8) cus = 8;
-  }
-  return cus;
-}
-int st_gemm_x3_stream(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K, int batch,
-                      hipStream_t s) {
-  const int MT = cdiv(M, 128), NT = N / 128;
-  const long long tiles = (long long)MT * NT * batch;
-  if (tiles >= (1ll << 30) || strideC < (long long)MT * 128 * ldc) return STROTSS_EINVAL;
-  int grid = stream_cus();
-  if (grid > tiles) grid = (int)tiles;
-  const __bf16* a = reinterpret_cast<const __bf16*>(A);
-  const __bf16* b = reinterpret_cast<const __bf16*>(B);
-  const long long sa = (long long)x3_panel_elems(M, K), sb = (long long)x3_panel_elems(N, K);
-#define X3S_LAUNCH(KS) hipLaunchKernelGGL((gemm_x3_stream_kernel<X3StreamCfg<KS>>), dim3((unsigned)grid), dim3(X3StreamCfg<KS>::NT), 0, s, a, M, \
-                                          sa, b, N, sb, C, ldc, strideC, MT, NT, (int)tiles)
-  if (K == 128) X3S_LAUNCH(8); else if (K == 256) X3S_LAUNCH(16); else X3S_LAUNCH(32);
-#undef X3S_LAUNCH
-  ST_LAUNCH_RET();
-}
 
 // C[z] (M x N, ldc) = A[z] B[z]^T, both operands as x3 panels of K columns (K % 32 == 0).
 // 128 x 128 tiles (one workgroup per CU) when there are at least `min_tiles128` of them, else 64 x 64 (two per CU): few

@@ -333,10 +333,9 @@ __device__ __forceinline__ SampleTap sample_tap(const strotss_maps_t& m, int k, 
       const int ra = x0 - m.row0[k], rb = x1 - m.row0[k];
       xa = min(max(ra, 0), m.rows[k] - 1);
       x1 = min(max(rb, 0), m.rows[k] - 1);
-      if (m.window_drop) {                          // adjoint of a halo-exchange strip: rows outside take nothing
-        if (ra != xa) { t.wa = 0.f; t.wb = 0.f; }
-        if (rb != x1) { t.wc = 0.f; t.wd = 0.f; }
-      }
+      // adjoint of a halo-exchange strip: rows outside take nothing (integer flags: no lane mask kept across the map loop)
+      if (m.window_drop & (int)(ra != xa)) { t.wa = 0.f; t.wb = 0.f; }
+      if (m.window_drop & (int)(rb != x1)) { t.wc = 0.f; t.wd = 0.f; }
     }
     t.ia = xa * w + y0; t.ib = xa * w + y1; t.ic = x1 * w + y0; t.id = x1 * w + y1;
   } else {
@@ -415,14 +414,22 @@ __global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m,
     const bool masked = k >= relu_mask_from;
     const int ii[4] = {t.ia, t.ib, t.ic, t.id};
     const float ww[4] = {t.wa, t.wb, t.wc, t.wd};
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
-      const float gv = g[off + ch];
+    // Wave-uniform trip count and a per-lane `in` test made afresh in every trip: no exec mask or tap predicate is kept in
+    // an SGPR pair across the channel loop (every saved mask below lives for the few instructions around one atomic).
+    for (int base = 0; base < c; base += 256) {
+      const int ch = base + (int)threadIdx.x;
+      const bool in = ch < c;
+      const int chc = in ? ch : c - 1;                                     // clamped: the load below is always in range
+      const float gv = in ? g[off + chc] : 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (ww[q] == 0.f) continue;
-        const size_t o = (size_t)ii[q] * c + ch;
-        if (masked && !(act[o] > 0.f)) continue;
-        atomicAdd(&dst[o], ww[q] * gv);
+        // The skip is decided per lane and per trip from the PRODUCT (a vector compare on a value made in this
+        // iteration), never from a wave-uniform `ww[q] == 0` test: the compiler kept that one as four lane masks in
+        // s[2:9] across the whole channel loop, and the build that lost whole (wave, tap) contributions next to another
+        // process was the one with tap 0's mask in s[2:3].  A zero product adds nothing.
+        const float v = ww[q] * gv;
+        const size_t o = (size_t)ii[q] * c + chc;
+        if (v != 0.f && (!masked || act[o] > 0.f)) atomicAdd(&dst[o], v);
       }
     }
     off += c;

@@ -26,11 +26,6 @@ int st_winograd43_pack(const float* u_prk, int rows, int k, float* u_packed, hip
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                         const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code,
                         const unsigned* bits_in, unsigned* bits_out, hipStream_t st);
-// winograd_gemm_out.hip: the 36 bf16x3 GEMMs of an F(4x4,3x3) layer with the output transform folded in (V as x3 panels)
-bool st_winograd43_gemm_out_enabled(size_t T, int cin, int cout);
-int st_winograd43_gemm_out(const void* V, const void* Ux3, size_t T, int cin, int cout, int h, int w, int TW,
-                           const float* bias, const float* mask, int relu, float* out, const unsigned* bits_in,
-                           unsigned* bits_out, hipStream_t st);
 int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, hipStream_t st);
 
 // f32 GEMM cores on the bf16 MFMA (mfma_x3.h): operands as "x3 panels" (3 * rows * K bf16 per batch entry)
@@ -48,10 +43,6 @@ int st_moment_bwd_x3(const void* Pc, int n, int ld, const void* Tp, float alpha,
                      float* dY, hipStream_t s);
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,
                        int batch, hipStream_t s, long min_tiles128 = 0);
-
-bool st_gemm_x3_stream_ok(int M, int N, int K, int batch);
-int st_gemm_x3_stream(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K, int batch,
-                      hipStream_t s);
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

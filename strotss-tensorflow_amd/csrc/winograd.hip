@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
                                                              float* __restrict__ out, int c4_shift, size_t Tstride,
                                                              const u32x4* __restrict__ bits_in, u32x4* __restrict__ bits_out,
                                                              f32x4* __restrict__ pool, unsigned* __restrict__ pool_code) {
-  // Tstride: tiles per position plane of Mw (>= TH * TW: the streaming GEMM pads the planes to whole 128-row tiles)
+  // Tstride: tiles per position plane of Mw (>= TH * TW)
   // bits_in / bits_out: sign words of the tile grid (include/strotss_hip.h: relu_bits), one per (tile, channel); with
   // bits_in the mask comes from them (16 bytes per thread instead of 16 x 16 bytes of activations)
   // pool (forward): also the 2x2/2 max-pool of the result and (pool_code) its argmax codes, exactly as maxpool2_fwd_kernel
@@ -377,31 +377,18 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
   if (T * (size_t)(max(cin, cout) / 4 + 8) >= (1ull << 32)) return STROTSS_ERANGE;     // 32-bit element indices in the transforms
   Workspace ws(workspace, workspace_bytes);
   float* V = ws.take<float>(36 * T * cin * 3 / 2);           // f32 V, or its x3 panels (3 bf16 per value)
-  const size_t Tpad = (T + 127) / 128 * 128;                 // the streaming GEMM stores whole 128-row tiles
-  float* Mw = ws.take<float>(36 * Tpad * cout);
+  float* Mw = ws.take<float>(36 * T * cout);
   if (!ws.ok()) return STROTSS_EINVAL;
   const size_t tout = T * (cout / 4);
-  size_t Tstride = T;
+  const size_t Tstride = T;
   int rc;
   const int stages = g_wino_stages;
   if (x3) {
     const size_t tin = ((T + 7) / 8) * 8 * (cin / 4);
     if (stages & 1) hipLaunchKernelGGL(winograd43_in_x3_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st,
                        in, h, w, cin / 4, TH, TW, reinterpret_cast<__bf16*>(V), log2_or_minus1(cin / 32));
-    // two-kernel form: the GEMMs of all 36 positions and the output transform in ONE kernel, no M tensor
-    if (st_winograd43_gemm_out_enabled(T, cin, cout))
-    {
-      rc = (stages & 2) ? st_winograd43_gemm_out(V, Ux3, T, cin, cout, h, w, TW, bias, mask, relu, out, bits_in, bits_out, st) : 0;
-      if (rc != 0 || !pool_out) return rc;
-      return st_maxpool2_fwd(out, h, w, cout, pool_out, pool_code, st);      // (that kernel's epilogue is one row of tiles wide)
-    }
     if (!(stages & 2)) rc = 0;
-    else if (st_gemm_x3_stream_ok((int)T, cout, cin, 36)) {          // one persistent pipeline per CU over all 36 x tiles
-      Tstride = Tpad;
-      rc = st_gemm_x3_stream(V, Ux3, Mw, cout, (long long)Tpad * cout, (int)T, cout, cin, 36, st);
-    } else {
-      rc = st_gemm_x3_batched(V, Ux3, Mw, cout, (long long)T * cout, (int)T, cout, cin, 36, st, x3_min_tiles());
-    }
+    else rc = st_gemm_x3_batched(V, Ux3, Mw, cout, (long long)T * cout, (int)T, cout, cin, 36, st, x3_min_tiles());
   } else {
     const size_t tin = T * (cin / 4);
     if (stages & 1) hipLaunchKernelGGL(winograd43_in_kernel, dim3((unsigned)min((size_t)16384, (tin + 255) / 256)), dim3(256), 0, st, in,
@@ -564,8 +551,6 @@ int strotss_conv3x3_winograd_route(int h, int w, int cin, int cout, int tile_m, 
   const bool prefer_x3 = has_x3 && cin % 32 == 0 && winograd43_prefers_x3(h, w, cout);
   if (!prefer_x3 && has_packed && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout)) return STROTSS_ROUTE_F4_FUSED_F32;
   if (!(has_x3 && cin % 32 == 0 && x3_enabled(T, cout))) return STROTSS_ROUTE_F4_GEMM_F32;
-  if (st_winograd43_gemm_out_enabled(T, cin, cout)) return STROTSS_ROUTE_F4_X3_GEMM_OUT;
-  if (st_gemm_x3_stream_ok((int)T, cout, cin, 36)) return STROTSS_ROUTE_F4_X3_STREAM;
   return (long)((T + 127) / 128) * ((cout + 127) / 128) * 36 >= x3_min_tiles() ? STROTSS_ROUTE_F4_X3_GEMM_128
                                                                              : STROTSS_ROUTE_F4_X3_GEMM_64;
 }

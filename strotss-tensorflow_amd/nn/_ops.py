@@ -176,7 +176,7 @@ def winograd_packed(u: torch.Tensor):
     """The fragment-major copy of a (36, rows, k) Winograd weight tensor for the fused kernel (made once per
     tensor object; the weights are frozen), or None where the fused kernel does not apply."""
     import weakref
-    if int(u.shape[0]) != 36 or int(u.shape[1]) % 32 or int(u.shape[2]) % 32:
+    if not winograd_packed_wanted(int(u.shape[0]), int(u.shape[1]), int(u.shape[2])):
         return None
     hit = _packed.get(id(u))
     if hit is not None and hit[0]() is u:
@@ -199,22 +199,32 @@ def _x3_min_tiles() -> int:
     return int(os.environ.get("STROTSS_X3_MIN_TILES", "1024"))
 
 
-def winograd_x3(u: torch.Tensor, h: int, w: int):
-    """The x3 panels (three bf16 planes per f32 weight, K-blocked; csrc/mfma_x3.h) of a (36, rows, k) Winograd weight
-    tensor for the bf16x3 GEMM core (made once per tensor object; the weights are frozen), or None where the library
-    would not use them for an (h, w) layer: same policy as csrc/winograd.hip x3_enabled (at least
-    STROTSS_X3_MIN_TILES 128 x 128 GEMM tiles) on the layers the fused kernel does not take (rows > 256)."""
-    import os, weakref
-    rows = int(u.shape[1])
+def winograd_x3_wanted(p: int, rows: int, k: int, h: int, w: int) -> bool:
+    """Whether the library would run an (h, w) layer with (p, rows, k) Winograd weights on the bf16x3 GEMM core: same policy
+    as csrc/winograd.hip x3_enabled (at least STROTSS_X3_MIN_TILES 64 x 64 GEMM tiles) on the layers the fused kernel
+    does not take.  Pure host arithmetic (tests/test_route_table.py pins it without a GPU)."""
+    import os
     tiles = -(-(-(-h // 4) * -(-w // 4)) // 64) * -(-rows // 64) * 36       # 64 x 64 tiles (csrc/winograd.hip x3_enabled)
-    if int(u.shape[0]) != 36 or int(u.shape[2]) % 32 or os.environ.get("STROTSS_X3", "1") == "0" \
+    if p != 36 or k % 32 or os.environ.get("STROTSS_X3", "1") == "0" \
             or os.environ.get("STROTSS_X3_CONV", "1") == "0":           # default on, see csrc/winograd.hip x3_enabled
-        return None
+        return False
     tiles128 = -(-(-(-h // 4) * -(-w // 4)) // 128) * -(-rows // 128) * 36
     fused_takes_it = (rows <= int(os.environ.get("STROTSS_WINO_FUSED_MAX_COUT", "256"))
                       and (rows < int(os.environ.get("STROTSS_X3_MIN_COUT", "256")) or tiles128 < _x3_min_tiles())
                       and os.environ.get("STROTSS_WINO_FUSED", "1") != "0")
-    if tiles < _x3_min_tiles() or fused_takes_it:
+    return not (tiles < _x3_min_tiles() or fused_takes_it)
+
+
+def winograd_packed_wanted(p: int, rows: int, k: int) -> bool:
+    return p == 36 and rows % 32 == 0 and k % 32 == 0
+
+
+def winograd_x3(u: torch.Tensor, h: int, w: int):
+    """The x3 panels (three bf16 planes per f32 weight, K-blocked; csrc/mfma_x3.h) of a (36, rows, k) Winograd weight
+    tensor for the bf16x3 GEMM core (made once per tensor object; the weights are frozen), or None where the library
+    would not use them for an (h, w) layer (`winograd_x3_wanted`)."""
+    import weakref
+    if not winograd_x3_wanted(int(u.shape[0]), int(u.shape[1]), int(u.shape[2]), h, w):
         return None
     hit = _x3.get(id(u))
     if hit is not None and hit[0]() is u:
@@ -439,6 +449,13 @@ def selfsim_fwd_bwd(pred, content, n, d, gscale, gpred, loss_out):
     ws = workspaces.get("selfsim", nb, pred.device)
     check(l.strotss_selfsim_fwd_bwd(ptr(pred), ptr(content), n, d, pred.shape[1], gscale, ptr(gpred),
                                     ptr(loss_out), ptr(ws), nb, stream_ptr()), "selfsim_fwd_bwd")
+    # what the workspace now holds (reciprocal norms + x3 panels of exactly these prediction rows), for the borrower below
+    global _selfsim_record
+    _selfsim_record = (ws.data_ptr(), nb, ptr(pred), n, int(pred.shape[1]), stream_ptr())
+
+
+_selfsim_record = None
+remd_borrow_stats = {"borrowed": 0, "plain": 0}      # which path remd_cos_fwd_bwd_after_selfsim took (tests read it)
 
 
 def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out):
@@ -450,18 +467,25 @@ def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out):
 
 
 def remd_cos_fwd_bwd_after_selfsim(style, rs, style_panels, ns, pred, n, d, gscale, gpred, loss_out):
-    """remd_cos_fwd_bwd for the prediction rows that selfsim_fwd_bwd has just processed (nothing else may have used the
-    "selfsim" workspace since): their reciprocal norms and x3 panels are taken from that workspace, the style rows' panels
+    """remd_cos_fwd_bwd for the prediction rows that selfsim_fwd_bwd has just processed (checked against the record that
+    call leaves; a mismatch -- other rows, a regrown workspace, another stream -- falls back to the plain call): their reciprocal norms and x3 panels are taken from that workspace, the style rows' panels
     from `style_panels` (row_inv_norm_x3(style)[1], constant within a scale) -- bit for bit remd_cos_fwd_bwd, one launch and
     two passes over the rows less.  style_panels None or the cost matrices on the f32 MFMA: the plain call."""
     l = _hip.lib()
     ld = pred.shape[1]
     nb = l.strotss_selfsim_workspace_bytes(n, ld)
     ws = workspaces.get("selfsim", nb, pred.device)
+    # borrow only what selfsim_fwd_bwd is KNOWN to have left there: same buffer (not regrown or re-used since), same rows,
+    # same count and stride, same stream -- anything else takes the plain call, which makes its own norms and panels
+    if _selfsim_record != (ws.data_ptr(), nb, ptr(pred), n, int(ld), stream_ptr()):
+        remd_borrow_stats["plain"] += 1
+        return remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out)
     rp, xp = C.c_void_p(), C.c_void_p()
     check(l.strotss_selfsim_pred_panels(ptr(ws), nb, n, ld, C.byref(rp), C.byref(xp)), "selfsim_pred_panels")
     if style_panels is None or not xp.value:
+        remd_borrow_stats["plain"] += 1
         return remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out)
+    remd_borrow_stats["borrowed"] += 1
     nbr = l.strotss_remd_workspace_bytes(ns, n, ld)
     wsr = workspaces.get("remd", nbr, pred.device)
     check(l.strotss_remd_cos_fwd_bwd_panels(ptr(style), ptr(rs), ptr(style_panels), ns, ptr(pred), rp.value, xp.value, n, d, ld,

@@ -64,7 +64,18 @@ class _Capture:
         return self
 
     def __exit__(self, *exc):
-        self.graph.capture_end()
+        if exc[0] is None:
+            try:
+                self.graph.capture_end()
+            finally:
+                self._ctx.__exit__(None, None, None)
+            return False
+        # the body raised: end the (now invalid) capture so the stream is usable again, but never let that second error
+        # replace the one the caller has to see
+        try:
+            self.graph.capture_end()
+        except Exception:
+            pass
         self._ctx.__exit__(*exc)
         return False
 
@@ -115,8 +126,11 @@ class StepEngine:
         self.group = dist_group
         self.rank, self.world = parallel.world_info(dist_group) if dist_group is not None else (0, 1)
         self.my_regions = parallel.regions_for_rank(self.R, self.rank, self.world)
+        # the sharded structure ([pixel gradient | scalars] in one buffer, graph | all-reduce | graph) also in a world of one
+        # when STROTSS_DIST_FORCE=1 asks for it (the RCCL rehearsal on one GPU)
+        self.sharded = dist_group is not None and (self.world > 1 or parallel.force_collectives())
         self._reduce_buf = None
-        if self.world > 1 and strips is None:
+        if self.sharded and strips is None:
             self._reduce_buf = torch.zeros(3 * h * w + self.R * 8, dtype=torch.float32, device=dev)
             self.trunk.gimg = self._reduce_buf[:3 * h * w].view(1, h, w, 3)
         self.d = 3 + sum(int(a.shape[-1]) for a in (self.trunk.acts[i] for i in self.trunk.taps))
@@ -175,14 +189,19 @@ class StepEngine:
         # deterministic mode (STROTSS_DETERMINISTIC=1): the tap adjoint as a sorted scatter, one plan per region and step
         # (no float atomics -> bitwise reproducible steps; the reference asks TF for the same: nn/rand.py:4-8)
         import os
-        # default: off with a GPU to itself; ON when several ranks share one card (parallel.ranks_share_a_gpu)
+        # default: off with a GPU to itself; ON when two ranks of the group sit on one card (parallel.ranks_share_a_gpu)
         env = os.environ.get("STROTSS_DETERMINISTIC")
         self.deterministic = bool(deterministic) if deterministic is not None else \
-            (env == "1" if env is not None else parallel.ranks_share_a_gpu())
+            (env == "1" if env is not None else parallel.ranks_share_a_gpu(dist_group))
         self._plans = None
         if self.deterministic:
             nb = _hip.lib().strotss_hypercol_scatter_plan_bytes(len(self.pred_maps))
             self._plans = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.R)]
+        # bench.py's measurement hook (strotss_debug_winograd_stages) is process-wide: an engine must never be built, captured
+        # or stepped under a partial stage mask, the convolutions would silently skip kernels
+        if _hip.lib().strotss_debug_winograd_stages(7) != 7:
+            raise _hip.StrotssHipError("strotss_debug_winograd_stages was left at a partial mask (a timing pass did not "
+                                       "restore it): results since then are meaningless")
         self.steps_done = 0
         self._graph = None
         self._graph_post = None           # sharded regions: the part of the step after the all-reduce
@@ -278,7 +297,7 @@ class StepEngine:
 
     def _pixel_gradient(self, indices: Sequence[torch.Tensor]) -> None:
         """fold, trunk forward, this rank's regions' samples + losses, trunk data-gradient -> trunk.gimg, scalars"""
-        if self.world > 1:
+        if self.sharded:
             self.scalars.zero_()          # regions owned by other ranks arrive through the all-reduce
         img = self.fold_forward()
         self.trunk.forward(img)
@@ -424,7 +443,7 @@ class StepEngine:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g, post = torch.cuda.CUDAGraph(), None
-        if self.world > 1:
+        if self.sharded:
             with _Capture(g, side):
                 self._pixel_gradient(self._graph_idx)
             post = torch.cuda.CUDAGraph()

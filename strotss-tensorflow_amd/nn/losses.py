@@ -1,7 +1,8 @@
 """Distance matrices and the three STROTSS losses -- mirrors the reference's nn/losses.py:4-105.
 
-Each loss is ONE fused forward+backward pass over the HIP kernels (cost-matrix GEMMs on the fp32
-MFMA, reductions, sparse backward); the autograd bridge stores d(loss)/d(prediction) computed in
+Each loss is ONE fused forward+backward pass over the HIP kernels (cost-matrix GEMMs on the bf16x3
+core of csrc/mfma_x3.h -- exact three-way bf16 split of the f32 operands, f32 accumulation; STROTSS_X3=0: the f32
+MFMA --, reductions, sparse backward); the autograd bridge stores d(loss)/d(prediction) computed in
 that pass and scales it by the incoming scalar gradient.  As in `run_strotss.py`, gradients flow
 to the *prediction* argument only: `x` for `self_similarity(x, y)`, `y` for
 `moment_matching(x, y)` and `relaxed_emd(x, y)`; asking for the other side raises."""

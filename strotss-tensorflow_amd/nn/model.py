@@ -120,6 +120,26 @@ def winograd_tile(h: int, w: int, cin: int = 128, cout: int = 0) -> int:
     return 2 if cin >= 128 else 0
 
 
+ROUTE_NAMES = {0: "F2_gemm_f32", 1: "F4_fused_f32", 2: "F4_gemm_f32", 3: "F4_x3_gemm_128", 4: "F4_x3_gemm_64"}
+
+
+def conv_route(h: int, w: int, cin: int, cout: int, dgrad: bool = False) -> str:
+    """Which kernels the generic 3x3 layer `cin` -> `cout` runs at (h, w), forward or data-gradient: the host policy above
+    (`winograd_tile`, one decision per layer for both directions, as VGGTrunk takes it) followed by the library's
+    (`strotss_conv3x3_winograd_route` / `strotss_conv3x3_workspace_bytes`, include/strotss_hip.h; the data-gradient is the
+    same kernel with the channel roles swapped).  No GPU needed: tests/test_route_table.py pins the default table of the
+    five BASELINE scales so that a policy regression cannot pass unnoticed."""
+    from . import _hip
+    t = winograd_tile(h, w, cin, cout) if use_winograd(cin, cout) else 0
+    ci, co = (cout, cin) if dgrad else (cin, cout)
+    if t == 0:
+        return "direct_splitk" if _ops.conv3x3_direct_splits(h, w, ci, co) else "direct"
+    p = 16 if t == 2 else 36
+    r = int(_hip.load_library().strotss_conv3x3_winograd_route(h, w, ci, co, t, int(_ops.winograd_packed_wanted(p, co, ci)),
+                                                               int(_ops.winograd_x3_wanted(p, co, ci, h, w))))
+    return ROUTE_NAMES[r]
+
+
 class _LazyWinograd:
     """u[m] = Winograd-domain weights (P, rows, k) of one layer and direction for tile size m, made on first use."""
 

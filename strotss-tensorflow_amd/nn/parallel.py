@@ -49,6 +49,15 @@ def world_info(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def force_collectives() -> bool:
+    """STROTSS_DIST_FORCE=1: join the process group and run every collective of a sharded step even in a world of ONE rank
+    (a one-rank all-reduce is legal RCCL).  This is how the `nccl` branch below, the graph | all-reduce | graph ordering of
+    a sharded step and the side-stream capture run on the one-GPU boxes this build is tested on
+    (tests/test_hip_nccl_world1.py); a world of one otherwise never touches torch.distributed."""
+    import os
+    return os.environ.get("STROTSS_DIST_FORCE", "0") == "1"
+
+
 def init_from_env(device_index=None):
     """Join the process group torchrun describes (RANK / WORLD_SIZE / MASTER_*): backend "nccl" (= RCCL over xGMI)
     unless STROTSS_DIST_BACKEND says otherwise (gloo: rehearsal of N ranks on one GPU or on the CPU).  Returns
@@ -56,7 +65,7 @@ def init_from_env(device_index=None):
     import os
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not force_collectives():
         return 0, 1
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -68,17 +77,50 @@ def init_from_env(device_index=None):
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
+        ranks_share_a_gpu(None)          # the identity all-gather happens HERE, where every rank is known to be present
     return dist.get_rank(), dist.get_world_size()
 
 
-def ranks_share_a_gpu() -> bool:
-    """True when the launcher put more ranks on this node than it has GPUs (LOCAL_WORLD_SIZE / WORLD_SIZE against
-    torch.cuda.device_count(), which does not touch the devices): a rehearsal of N ranks on one card.  The engine then
-    defaults to the sorted tap adjoint: next to ANOTHER process running the bf16x3 GEMM core one build of the
-    float-atomic kernel lost contributions (one process per GPU, the deployment, never shares)."""
-    import os
-    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return local > max(1, torch.cuda.device_count())
+_share_cache = {}
+
+
+def device_identity(index=None) -> str:
+    """host name + the physical identity of this process's current device (uuid, else PCI bus id): equal strings on two
+    ranks = one card.  Unaffected by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumbering, unlike device counts."""
+    import socket
+    if not torch.cuda.is_available():
+        return f"{socket.gethostname()}:cpu"
+    p = torch.cuda.get_device_properties(torch.cuda.current_device() if index is None else index)
+    ident = getattr(p, "uuid", None) or getattr(p, "pci_bus_id", None)
+    if ident is None:
+        ident = f"{getattr(p, 'pci_domain_id', 0)}:{getattr(p, 'pci_bus_id', '?')}:{getattr(p, 'pci_device_id', '?')}"
+    return f"{socket.gethostname()}:{ident}"
+
+
+def ranks_share_a_gpu(group=None) -> bool:
+    """True when two ranks of the process group run on the SAME physical card (a rehearsal of N ranks on one GPU): decided
+    from the devices' identities, all-gathered once per group -- not from device counts, which a launcher that masks every
+    rank to one device (HIP_VISIBLE_DEVICES) makes 1 on a correct 8-ranks-on-8-GPUs node.  The engine then defaults to the
+    sorted tap adjoint (the float-atomic one lost contributions next to another process in one build; the
+    kernel has since been rewritten so that no long-lived lane mask decides a tap, the precaution stays).  Without a
+    process group there is nothing to compare: False (independent jobs sharing a card cannot be seen from here; set
+    STROTSS_DETERMINISTIC=1 for those).  Collective on first use per group: every rank builds its engine."""
+    import logging
+    import torch.distributed as dist
+    g = resolve_group(group)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(g) <= 1:
+        return False
+    key = id(g)
+    if key not in _share_cache:
+        mine = device_identity()
+        everyone = [None] * dist.get_world_size(g)
+        dist.all_gather_object(everyone, mine, group=g)
+        shared = len(set(everyone)) < len(everyone) and not mine.endswith(":cpu")
+        _share_cache[key] = shared
+        if shared and dist.get_rank(g) == 0:
+            logging.getLogger("strotss").warning("ranks share a GPU (%s): the tap adjoint defaults to the sorted, atomic-free "
+                                                 "form (STROTSS_DETERMINISTIC=0 overrides)", sorted(everyone))
+    return _share_cache[key]
 
 
 def regions_for_rank(n_regions: int, rank: int, world: int) -> List[int]:
@@ -90,7 +132,7 @@ def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum over the ranks (RCCL all-reduce over xGMI on GPU tensors; gloo on CPU)."""
     import torch.distributed as dist
     group = resolve_group(group)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collectives()):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 

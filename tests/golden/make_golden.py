@@ -99,6 +99,54 @@ def trace_fixture():
     np.savez_compressed(os.path.join(HERE, "trace_64px.npz"), **out)
 
 
+def trajectory_inputs():
+    """the seeded inputs of the 200-step trajectory (shared with tests/test_golden_gpu.py, which re-derives them)"""
+    h = w = 64
+    cfg = dict(h=h, w=w, n_samples=1024, steps=200, alpha=16.0, lr=2e-3, seed=7)
+    cfg["denom"] = 2.0 + cfg["alpha"] + 1.0 / max(cfg["alpha"], 1.0)
+    return cfg, img(h, w, 41), img(h, w, 42)
+
+
+def trajectory_fixture():
+    """200 free-running RMSprop steps of ONE 64-px scale in float64 (run_strotss.py:131-155: train_step + apply_gradients,
+    first-scale initialisation and alpha, N = 1024 samples of the 4096 candidates, a fresh index set per step from one
+    seeded stream, seeded synthetic VGG16): the loss curve and the final image the HIP engine is compared with
+    (tests/test_golden_gpu.py::test_200_step_trajectory_against_the_float64_oracle).  The index sets are not stored: the
+    product's own draw (nn.strotss_utils.make_indices_np) is bit-equal to the oracle's (tests/test_index_parity.py); their
+    checksum is."""
+    cfg, content, style = trajectory_inputs()
+    h, w, n, steps = cfg["h"], cfg["w"], cfg["n_samples"], cfg["steps"]
+    weights = O.make_synthetic_vgg16_weights(0)
+    vgg = O.VGG(weights, dtype=torch.float64)
+    rng = np.random.default_rng(cfg["seed"])
+    s_idx = O.make_indices(h, w, False, n, rng)
+    with torch.no_grad():
+        cf = [content] + vgg(content)
+        sf = [style] + vgg(style)
+        ss = O.sample_features(sf, s_idx, False)
+    init = O.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
+    variables = [v.clone().requires_grad_(True) for v in O.make_laplacian_pyramid(init)]
+    rms = [torch.zeros_like(v) for v in variables]
+    trace, idx_sum = [], 0.0
+    import time
+    t0 = time.time()
+    for it in range(steps):
+        idx = O.make_indices(h, w, True, n, rng)
+        idx_sum += float((idx.astype(np.float64) * (np.arange(idx.size).reshape(idx.shape) % 97 + 1)).sum())
+        res = O.train_step(variables, vgg, cf, ss, idx, cfg["alpha"], cfg["denom"])
+        with torch.no_grad():
+            for v, r, g in zip(variables, rms, res["grads"]):
+                O.rmsprop_update(v, r, g, cfg["lr"])
+        trace.append([float(res["loss"]), float(res["loss_c"]), float(res["loss_s"])])
+        if it % 20 == 0:
+            print(f"trajectory step {it}: loss {trace[-1][0]:.5f}  ({time.time() - t0:.0f} s)", flush=True)
+    final = O.fold_laplacian_pyramid([v.detach() for v in variables])
+    np.savez_compressed(os.path.join(HERE, "trajectory_64px_200.npz"), trace=np.array(trace), final=final.numpy().astype(np.float32),
+                        final_u8=O.postprocess(final), style_idx_sum=float(s_idx.astype(np.float64).sum()), idx_checksum=idx_sum,
+                        init_u8=O.postprocess(init),
+                        weight_checksum=float(sum(float(w_.double().sum() + b.double().sum()) for w_, b in weights)))
+
+
 def image_fixture():
     """bilinear resize / pyramid / sampling known outputs on a tiny non-square image."""
     x = img(21, 32, 31)
@@ -117,12 +165,19 @@ if __name__ == "__main__" and "--jpeg-only" in sys.argv:
     jpeg_fixture()
     sys.exit(0)
 
+if __name__ == "__main__" and "--trajectory-only" in sys.argv:      # ~ten minutes of float64 CPU work
+    torch.set_num_threads(8)
+    trajectory_fixture()
+    sys.exit(0)
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     losses_fixture()
     image_fixture()
     trace_fixture()
     jpeg_fixture()
+    if "--with-trajectory" in sys.argv:
+        trajectory_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

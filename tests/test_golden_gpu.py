@@ -86,3 +86,58 @@ def test_trace_against_fixture():
     # the oracle's float32 arithmetic on the float32 cast of `final`, which is what dev() uploads)
     u8 = SU.postprocess(dev(z["final"])).cpu().numpy()
     assert u8.dtype == np.uint8 and np.array_equal(u8, z["final_u8"]), int((u8 != z["final_u8"]).sum())
+
+
+def test_200_step_trajectory_against_the_float64_oracle():
+    """north_star's "matching output pixels within a stated tolerance": 200 FREE-RUNNING steps of one 64-px scale (no
+    re-synchronisation) on the HIP engine -- deterministic tap adjoint, the same seeded index stream, seeded weights --
+    against the float64 oracle's trajectory committed in tests/golden/trajectory_64px_200.npz (generator:
+    make_golden.py --trajectory-only; reference loop: run_strotss.py:131-155).  Bit equality is out of reach (RMSprop's first
+    update is 10*lr*sign(g), the L1 / hard-min losses flip signs and arg-mins on f32 rounding); what is asserted is what
+    DESIGN.md 6 states as the tolerance: the loss curve within LOSS_TOL of the oracle's at every step from step 20 on, and
+    the final uint8 image at PSNR >= PSNR_MIN dB of the oracle's."""
+    from nn import _ops, engine, strotss_utils as SU
+    from nn.model import VGGParams, synthetic_weights
+    z = np.load(os.path.join(G, "trajectory_64px_200.npz"))
+    # the inputs are re-derived from their seeds exactly as the generator does (trajectory_inputs); only torch + numpy
+    def img(h, w, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(1, h, w, 3, generator=g, dtype=torch.float64)
+        return torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1).contiguous()
+    h = w = 64
+    n, steps, alpha, lr, seed = 1024, 200, 16.0, 2e-3, 7
+    denom = 2.0 + alpha + 1.0 / max(alpha, 1.0)
+    content, style = img(h, w, 41).float().to(DEV), img(h, w, 42).float().to(DEV)
+    weights = synthetic_weights('16', 0)
+    assert abs(float(sum(float(w_.double().sum() + b.double().sum()) for w_, b in weights)) - float(z["weight_checksum"])) < 1e-9
+    params = VGGParams(weights, '16', None, DEV)
+    cfeat = engine.extract_features(params, content)
+    sfeat = engine.extract_features(params, style)
+    rng = np.random.default_rng(seed)
+    s_idx = SU.make_indices_np(h, w, False, n, rng)
+    assert float(s_idx.astype(np.float64).sum()) == float(z["style_idx_sum"])
+    target = engine.StyleTarget.build(_ops.hypercol_gather(sfeat, dev(s_idx), False), n, 2179)
+    init = SU.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
+    assert np.abs(SU.postprocess(init).cpu().numpy().astype(int) - z["init_u8"].astype(int)).max() <= 1   # f32 vs f64 start image
+    eng = engine.StepEngine(params, cfeat, [target], init, alpha, denom, lr, sample_size=n, deterministic=True)
+    trace, idx_sum = [], 0.0
+    for it in range(steps):
+        idx = SU.make_indices_np(h, w, True, n, rng)
+        idx_sum += float((idx.astype(np.float64) * (np.arange(idx.size).reshape(idx.shape) % 97 + 1)).sum())
+        eng.step([dev(idx)])
+        got = eng.losses()
+        trace.append([got["loss"], got["loss_c"], got["loss_s"]])
+    assert idx_sum == float(z["idx_checksum"])                     # the same 200 index sets as the oracle's run
+    trace, ref = np.array(trace), z["trace"]
+    rel = np.abs(trace[:, 0] - ref[:, 0]) / np.abs(ref[:, 0])
+    u8 = SU.postprocess(eng.stylized()).cpu().numpy().astype(np.float64)
+    mse = float(((u8 - z["final_u8"].astype(np.float64)) ** 2).mean())
+    psnr = 10.0 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    mean_abs = float(np.abs(eng.stylized().cpu().numpy() - z["final"]).mean())
+    print(f"TRAJECTORY 200 steps @64px: loss rel err max(first 20) {rel[:20].max():.3e}, max(20..) {rel[20:].max():.3e}, "
+          f"mean {rel.mean():.3e}, final loss {trace[-1, 0]:.6f} vs {ref[-1, 0]:.6f}; final image PSNR {psnr:.2f} dB, "
+          f"mean |d| {mean_abs:.5f}, bytes differing {int((u8 != z['final_u8']).sum())} of {u8.size}")
+    LOSS_TOL, PSNR_MIN = 2e-2, 30.0
+    assert rel[:20].max() < 5e-2, rel[:20].max()                   # the sign-like first updates
+    assert rel[20:].max() < LOSS_TOL, (int(rel[20:].argmax()) + 20, rel[20:].max())
+    assert psnr >= PSNR_MIN, psnr

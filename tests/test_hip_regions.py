@@ -72,35 +72,3 @@ def test_bench_regions_mode_two_ranks_prints_n_gpus_2():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert "4 mask regions" in line["config"]["workload"] and "all-reduce" in line["config"]["parallelism"]
-
-
-def test_float_atomic_tap_adjoint_next_to_another_process_running_the_x3_gemm(tmp_path):
-    """The shared-GPU finding of DESIGN.md 6, kept as a regression test of the DEFAULT (float-atomic) tap adjoint: one
-    build of `hypercol_scatter_kernel` lost whole (wave, tap) contributions in 199 of 200 launches while ANOTHER process
-    ran the bf16x3 GEMM core (LDS-DMA between bf16 MFMAs; `strotss_moment_stats` in a loop) on the same GPU -- and in
-    none next to the same loop with STROTSS_X3=0.  The current build has not shown it; this test runs the strongest
-    aggressor found next to every repeatable kernel family of the step and asserts that nothing changes."""
-    stop = tmp_path / "stop"
-    neigh = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "x3_neighbour.py"), str(stop), "200", "mstats"],
-                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    try:
-        import time
-        t0 = time.time()
-        while not os.path.exists(str(stop) + ".ready"):
-            assert neigh.poll() is None, neigh.communicate()[0][-2000:]
-            assert time.time() - t0 < 180, "neighbour did not come up"
-            time.sleep(0.5)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cross_process_probe.py"), "60"],
-                             capture_output=True, text=True, timeout=400)
-        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-        lines = {l.split(":")[0]: l for l in out.stdout.splitlines() if ": wrong in " in l}
-        assert set(lines) == {"atomic_scatter", "sorted_scatter", "gather", "trunk_forward", "losses", "deterministic_step"}
-        for name, l in lines.items():
-            assert ": wrong in 0 of 60" in l, l
-    finally:
-        stop.write_text("1")
-        try:
-            text = neigh.communicate(timeout=60)[0]
-        except subprocess.TimeoutExpired:
-            neigh.kill(); text = neigh.communicate()[0]
-    assert "neighbour mstats iterations" in text, text[-2000:]          # the aggressor really ran beside the probe

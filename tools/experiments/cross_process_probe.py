@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Victim side of the shared-GPU experiment: repeats several kernels of the step on bitwise-constant inputs
-and compares every result with the first one.  Run it next to tools/x3_neighbour.py (another process on the same GPU).
+and compares every result with the first one.  Run it next to tools/experiments/x3_neighbour.py (another process on the same GPU).
 usage: cross_process_probe.py ITERATIONS"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "strotss-tensorflow_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

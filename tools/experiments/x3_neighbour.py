@@ -4,7 +4,7 @@ appears.  The part that makes a co-resident process's float-atomic tap adjoint l
 core (LDS-DMA between bf16 MFMAs): `mstats` (strotss_moment_stats: centring + the 128 x 128-tile covariance GEMM).
 usage: x3_neighbour.py STOPFILE SECONDS [full|fwd|bwd|loss|mstats|cosx3|normx3|gather|fold|scat]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "strotss-tensorflow_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

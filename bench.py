@@ -124,8 +124,75 @@ def strip_index_stream(scale, count, rng, dev, plan, sample_size=SAMPLES, region
 
 
 def run_steps(eng, idx, first, count):
+    if eng._draw is not None:                 # the step draws its own index sets on the device (csrc/draw.hip)
+        for _ in range(count):
+            eng.step()
+        return
     for i in range(first, first + count):
         eng.step(list(idx[i % idx.shape[0]]))
+
+
+# reference device for `normalised`: the nominal figures of MI355X_MICROARCH.md (f32 MFMA 155 TF measured back to back,
+# bf16 2.5 PF dense x the ~0.9 a register-only loop holds, copy 6.29 TB/s): a box that calibrates exactly there is left
+# unchanged.  Weights = the shares of a 1024-px step by what bounds them (fused f32 Winograd kernel + first
+# layer ~0.43, bf16x3 GEMMs ~0.32, transform / pooling / gather / fold kernels ~0.25).
+CALIB_REF = {"mfma_f32": 155.0, "mfma_bf16": 2250.0, "copy": 5000.0}
+CALIB_WEIGHTS = {"mfma_f32": 0.43, "mfma_bf16": 0.32, "copy": 0.25}
+
+
+def normalise(steps_per_sec, calib):
+    """steps/s this run would show on the reference device: every share of the step time is scaled by the box's measured
+    rate for its bound (time_ref = time_box * sum_k w_k * box_k / ref_k)."""
+    if not calib:
+        return None
+    rates = {"mfma_f32": calib["mfma_f32"]["tflops"], "mfma_bf16": calib["mfma_bf16"]["tflops"],
+             "copy": calib["copy"]["GBps_read_plus_write"]}
+    scale = sum(CALIB_WEIGHTS[k] * rates[k] / CALIB_REF[k] for k in rates)
+    return {"steps_per_sec": round(steps_per_sec / scale, 2), "time_scale_box_over_reference": round(1.0 / scale, 4),
+            "model": "time_ref = time_box * sum_k w_k * rate_box_k / rate_ref_k", "weights": CALIB_WEIGHTS, "reference": CALIB_REF}
+
+
+def box_calibration(dev):
+    """What THIS box sustains, measured right after the timed steps (warm chip): a ~45-ms register-only f32-MFMA loop and
+    a ~45-ms bf16-MFMA loop (one wave per SIMD, every CU; rate and the clock the device held = s_memtime / s_memrealtime,
+    median over workgroups) and a 256-MB streaming copy.  Boxes of the pool differ by up to 5 % in steps/s on one binary;
+    these three numbers are what `normalised` is computed from."""
+    from nn import _hip
+    lib = _hip.lib()
+    blocks = 256
+    sink = torch.empty(blocks * 256, dtype=torch.float32, device=dev)
+    clk = torch.zeros(2 * blocks, dtype=torch.int64, device=dev)
+    st = _hip.stream_ptr()
+    out = {}
+    for name, bf16, iters, flop in (("mfma_f32", 0, 100000, 4096.0), ("mfma_bf16", 1, 200000, 32768.0)):
+        _hip.check(lib.strotss_calib_mfma(bf16, blocks, 2000, sink.data_ptr(), clk.data_ptr(), st), "calib")     # code load
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _hip.check(lib.strotss_calib_mfma(bf16, blocks, iters, sink.data_ptr(), clk.data_ptr(), st), "calib")
+            e1.record(); e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            c = clk.cpu().numpy().reshape(blocks, 2).astype(np.float64)
+            ghz = float(np.median(c[:, 0] / np.maximum(c[:, 1], 1.0)) * 0.1)
+            tf = blocks * 4 * iters * 16.0 * flop / (ms * 1e-3) / 1e12
+            if best is None or tf > best[0]:
+                best = (tf, ghz, ms)
+        out[name] = {"tflops": round(best[0], 1), "clock_ghz": round(best[1], 3), "ms": round(best[2], 2)}
+    nbytes = 256 << 20
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+    a.fill_(1)
+    _hip.check(lib.strotss_calib_copy(a.data_ptr(), b.data_ptr(), nbytes, st), "calib_copy")
+    best = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _hip.check(lib.strotss_calib_copy(a.data_ptr(), b.data_ptr(), nbytes, st), "calib_copy")
+        e1.record(); e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    out["copy"] = {"GBps_read_plus_write": round(2.0 * nbytes / (best * 1e-3) / 1e9, 1), "ms": round(best, 4), "MB": nbytes >> 20}
+    return out
 
 
 FAMILIES = ["conv3x3_relu_fwd", "conv3x3_dgrad", "conv3x3_winograd_fwd", "conv3x3_winograd_dgrad", "selfsim_fwd_bwd",
@@ -673,8 +740,10 @@ def rehearse(args, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--host-draw", action="store_true", help="pre-drawn, pre-uploaded index sets (rounds 1-3) instead of the "
+                                                             "draw kernel at the head of every timed step")
     ap.add_argument("--scale", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true")
@@ -738,8 +807,16 @@ def main():
         run_steps = lambda e, ix, first, n: [e.step(ix[i % len(ix)], offsets[i % len(ix)]) for i in range(first, first + n)]
     else:
         idx = index_stream(S, count, rng, dev, regions=regions)
+    # the step's index sets are drawn INSIDE the timed step, on the device (first node of the step's graph), as the
+    # reference draws them inside its traced train_step (strotss_utils.py:83-121 via run_strotss.py:136); image strips
+    # keep the host draw (every set is ordered by owning rank on the host)
+    drawn = (strips is None and not args.host_draw
+             and eng.enable_device_draw(0 if one_job else rank, 1000, region_masks(S, regions)))
     if not args.no_graph:
-        eng.capture_graph(list(idx[0]), offsets[0] if strips is not None else None)
+        if drawn:
+            eng.capture_graph()
+        else:
+            eng.capture_graph(list(idx[0]), offsets[0] if strips is not None else None)
 
     run_steps(eng, idx, 0, args.warmup)
     torch.cuda.synchronize()
@@ -756,6 +833,17 @@ def main():
     if one_job:
         value /= world                    # ONE job: its steps are not multiplied by the ranks
     losses = eng.losses()
+    # a window long enough to compare across runs whatever --steps was (the driver asks for 20 = 0.09 s): >= 200 replays
+    long_window = None
+    if world == 1:
+        n_long = max(200, args.steps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(eng, idx, args.warmup + args.steps, n_long)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        long_window = {"steps": n_long, "ms_per_step": round(1e3 * el / n_long, 4), "steps_per_sec": round(n_long / el, 2)}
+    calib = box_calibration(dev) if rank == 0 else None
 
     out = None
     if rank == 0:
@@ -778,7 +866,12 @@ def main():
                                       f"{SAMPLES} samples x D={D}, VGG16 (seeded He-normal weights), "
                                       f"RMSprop pixel update" + (f", {regions} mask regions" if regions > 1 else ""),
                           "scale_px": S, "samples": SAMPLES, "parallelism": par_desc},
-               "loss_after": round(losses["loss"], 5), "launch_mode": graph_mode}
+               "loss_after": round(losses["loss"], 5), "launch_mode": graph_mode,
+               "index_draw": ("inside the timed step: strotss_index_draw is the first kernel of every step's graph (Philox "
+                              "stream, csrc/draw.hip; reference: strotss_utils.py:83-121 inside the traced step)" if drawn else
+                              "outside the timed region: index sets drawn on the host and uploaded before the timed steps"),
+               "long_window": long_window, "box_calibration": calib}
+        out["normalised"] = normalise(long_window["steps_per_sec"] if long_window else value, calib)
         if world == 1 and strips is None and not args.no_families:
             # ---- per-kernel-family HIP-event timing (separate, untimed pass; eager launches, medians)
             saved_graph, eng._graph = eng._graph, None
@@ -868,13 +961,14 @@ def main():
         for s in (64, 128, 256, 512):
             e, r = build_engine(params, s, dev, seed=0)
             ix = index_stream(s, 16, r, dev)
+            e_drawn = not args.host_draw and e.enable_device_draw(0, 1000, None)
             if not args.no_graph:
-                e.capture_graph(list(ix[0]))
-            n = 30 if s <= 256 else 15
-            run_steps(e, ix, 0, 3)
+                e.capture_graph(None if e_drawn else list(ix[0]))
+            n = 200 if s <= 256 else 100
+            run_steps(e, ix, 0, 10)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_steps(e, ix, 3, n)
+            run_steps(e, ix, 10, n)
             torch.cuda.synchronize()
             sps = n / (time.perf_counter() - t1)
             pyr[str(s)] = round(sps, 2)
@@ -887,13 +981,6 @@ def main():
                               "projected_optimisation_wall_clock_s_5x200": round(total, 2)}
     if rank == 0 and not args.no_e2e and world == 1 and S == 1024 and args.mode == "replicas":
         out["wall_clock_to_output"] = wall_clock_to_output(dev)
-    if rank == 0:
-        cli = (out.get("wall_clock_to_output") or {}).get("cli_steps_per_sec_by_scale", {}).get(str(S))
-        out["index_draw"] = ("outside the timed region: the step's index sets (strotss_utils.py:83-121, drawn inside the "
-                             "reference's traced step) are drawn and uploaded before the timed steps; the CLI, which draws one "
-                             "set per step on the host and uploads it asynchronously, runs "
-                             + (f"{cli} it/s at this scale in the same process (graph capture included)" if cli
-                                else "within 1 % of this rate (see wall_clock_to_output when it is enabled)"))
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.mode == "replicas":
         out["cpu_baseline"] = cpu_baseline(S)
     if rank == 0:

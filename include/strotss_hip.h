@@ -238,6 +238,44 @@ int strotss_hypercol_scatter_sorted(const strotss_maps_t* maps, const void* plan
                                     int relu_mask_from, int map_begin, int map_end, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Box calibration (bench.py only; nothing on the product path calls these).  strotss_calib_mfma: `blocks` workgroups of
+ * four waves, each wave 16 * iters register-only v_mfma_f32_32x32x2_f32 (bf16 == 0: 4096 FLOP each) or
+ * v_mfma_f32_32x32x16_bf16 (bf16 != 0: 32768 FLOP each); sink: blocks * 256 floats; clocks: per workgroup
+ * {s_memtime ticks, s_memrealtime ticks (100 MHz)} of the loop -> the clock the device held.  strotss_calib_copy: a plain
+ * 16-byte-per-lane streaming copy of `bytes` (a multiple of 16).
+ * --------------------------------------------------------------------------------------- */
+int strotss_calib_mfma(int bf16, int blocks, int iters, float* sink, unsigned long long* clocks, void* stream);
+int strotss_calib_copy(const void* src, void* dst, size_t bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sample coordinates drawn on the device  (Sampling._make_indices, nn/strotss_utils.py:83-121; the reference draws
+ * them inside the traced train_step, run_strotss.py:136 / 115).  Region r (one workgroup each) reads its draw number
+ * t = counter[r], draws the grid offsets (k = 0 rows, 1 columns:  philox4x32-10(ctr = (k, 1, t, 0), key = seed)[0] mod
+ * step), lists the candidates (off_x + a*step_x, off_y + b*step_y) in tf.meshgrid('xy') order (a fastest), keeps those
+ * whose mask byte is nonzero (mask[r] == NULL: all), gives position j of the kept list the shuffle key
+ * philox(ctr = (j >> 2, 0, t, 0))[j & 3], writes the min(sample_size, kept) positions with the smallest (key, j) in
+ * ascending order as float32 (row, col) pairs to idx[r] (rows beyond that count: zeros) and the count to n_out[r], and
+ * stores counter[r] = t + counter_stride.  nn/rand.py:PhiloxStream is the host twin (same numbers through a
+ * NumPy-Generator interface), so the oracle's make_indices reproduces every draw.  sample_size <= 1024; the grid has at
+ * most 32768 candidates for any image (strotss_index_draw_max_candidates: STROTSS_ERANGE beyond that).
+ * --------------------------------------------------------------------------------------- */
+#define STROTSS_DRAW_MAX_REGIONS 16
+typedef struct strotss_draw_t {
+  int h, w;                       /* the scale's image size                                        */
+  int step_x, step_y;             /* strotss_utils.py:89-90: max(1, floor / ceil(sqrt(h*w // 128^2))) */
+  int sample_size;
+  int n_regions;
+  unsigned seed_lo, seed_hi;      /* Philox key                                                    */
+  unsigned counter_stride;        /* one stream whose draws interleave over the regions: n_regions */
+  const unsigned char* mask[STROTSS_DRAW_MAX_REGIONS];   /* (h, w) bytes at THIS scale, or NULL    */
+  float* idx[STROTSS_DRAW_MAX_REGIONS];                  /* (sample_size, 2) float32               */
+  unsigned* counter;              /* n_regions draw numbers in device memory                       */
+  int* n_out;                     /* n_regions counts, or NULL                                     */
+} strotss_draw_t;
+int strotss_index_draw_max_candidates(int h, int w, int step_x, int step_y);
+int strotss_index_draw(const strotss_draw_t* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Pairwise / moment losses  (nn/losses.py:12-80, run_strotss.py:21-40).
  * Every loss entry computes the loss value AND d(loss)/d(pred) scaled by `gscale`, added
  * into gpred (which the caller zero-fills once per step).  Scalars land in a device array.

@@ -440,14 +440,14 @@ def scale_schedule(level: int, start_level: int = 0):
 def run_scales(content: torch.Tensor, style: torch.Tensor, weights, *, level: int = 4,
                start_level: int = 0, max_iter: int = 200, lr: float = 2e-3,
                alpha: float = 1.0, seed: int = 0, sample_size: int = 1024,
-               dtype=torch.float32, index_stream=None, trace=None, scale_trace=None, previous_override=None):
+               dtype=torch.float32, index_stream=None, trace=None, scale_trace=None, previous_override=None, rng=None):
     """The coarse-to-fine driver of run_strotss.py:43-161 (no masks) on CPU tensors.
     `index_stream(scale_i, it, h, w)` may inject the (n,2) indices; by default they come
-    from make_indices with np.random.default_rng(seed).  Returns the float stylised image.
+    from make_indices with `rng` (default np.random.default_rng(seed)).  Returns the float stylised image.
     `scale_trace` (a list) receives per executed scale dict(i, scl, lr, alpha, loss_denom, init, final);
     `previous_override(i)` may return the image to take as the previous scale's result at scale i (tests
     re-synchronise free-running trajectories with it), or None to keep the oracle's own."""
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed) if rng is None else rng     # (any object with integers / permutation: make_indices)
     vgg = VGG(weights, dtype=dtype)
     content = content.to(dtype); style = style.to(dtype)
     a = alpha * 16.0 / 2.0 ** start_level      # alpha is halved after every scale of the schedule, skipped ones included

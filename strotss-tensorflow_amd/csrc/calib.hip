@@ -1,0 +1,80 @@
+// Box calibration for bench.py: three tiny kernels whose rates say what THIS device sustains, so that bench lines taken on
+// different boxes of the pool can be compared (boxes differ by up to 5 % in steps/s on the same binary; a register-only MFMA
+// loop on random-ish operands differs by up to 12 % between MI355X devices -- MI355X_MICROARCH.md, "DVFS give-back" (5)).
+// Nothing here is on the product path (the metric's step is run_strotss.py:131-148 of the reference).
+#include "internal.h"
+
+namespace {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// one wave per SIMD, four independent accumulator chains, operands in registers: the dense f32 MFMA rate and the clock held
+__global__ __launch_bounds__(256) void calib_mfma_f32_kernel(float* __restrict__ sink, int iters, unsigned long long* __restrict__ clk) {
+  f32x16_t a0 = {}, a1 = {}, a2 = {}, a3 = {};
+  const float x = threadIdx.x * 1e-3f + 1.0f, y = 0.5f + blockIdx.x * 1e-4f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0;
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  sink[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+__global__ __launch_bounds__(256) void calib_mfma_bf16_kernel(float* __restrict__ sink, int iters, unsigned long long* __restrict__ clk) {
+  f32x16_t a0 = {}, a1 = {}, a2 = {}, a3 = {};
+  bf16x8_t x, y;
+  for (int k = 0; k < 8; ++k) {            // values with full bf16 mantissas, different per lane (power depends on the data)
+    x[k] = (__bf16)(1.0f + 0.0078125f * (float)((threadIdx.x * 7 + k * 13) & 127));
+    y[k] = (__bf16)(0.5f + 0.00390625f * (float)((threadIdx.x * 11 + k * 5 + blockIdx.x) & 127));
+  }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, x, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, y, a3, 0, 0, 0);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0;
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  sink[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+// 16 bytes per lane, grid-stride: a plain streaming copy
+__global__ __launch_bounds__(256) void calib_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int strotss_calib_mfma(int bf16, int blocks, int iters, float* sink, unsigned long long* clocks, void* stream) {
+  ST_CHECK_ARG(sink && clocks && blocks > 0 && blocks <= 4096 && iters > 0, STROTSS_EINVAL);
+  if (bf16) hipLaunchKernelGGL(calib_mfma_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sink, iters, clocks);
+  else hipLaunchKernelGGL(calib_mfma_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sink, iters, clocks);
+  ST_LAUNCH_RET();
+}
+
+int strotss_calib_copy(const void* src, void* dst, size_t bytes, void* stream) {
+  ST_CHECK_ARG(src && dst && bytes >= 16 && bytes % 16 == 0, STROTSS_EINVAL);
+  hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(src),
+                     reinterpret_cast<f32x4*>(dst), bytes / 16);
+  ST_LAUNCH_RET();
+}
+
+}  // extern "C"

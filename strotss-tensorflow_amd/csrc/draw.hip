@@ -1,0 +1,247 @@
+// Sample coordinates of a train step drawn ON THE DEVICE (reference: Sampling._make_indices, nn/strotss_utils.py:83-121,
+// called inside the traced train_step at run_strotss.py:136 / 115): random grid offsets, strided candidate grid in
+// tf.meshgrid('xy') order, optional mask filter, joint shuffle of the (row, col) pairs, first `sample_size`.
+//
+// The random numbers are COUNTER-BASED (Philox4x32-10, the generator family behind tf.random.Generator; not TF's stream, which
+// cannot be reproduced without TF): draw number t of a stream with key (seed_lo, seed_hi) uses
+//     offset k (0: rows, 1: columns)     philox(ctr = (k, 1, t, 0))[0] mod step
+//     shuffle key of position j          philox(ctr = (j >> 2, 0, t, 0))[j & 3]        (j = position in the FILTERED list)
+// and "shuffle, take the first n" = the n positions with the smallest (key, j), in ascending order.  nn/rand.py:PhiloxStream
+// is the host twin: a NumPy-Generator look-alike (integers / permutation) that the oracle's make_indices consumes
+// unchanged, so tests/test_index_parity.py compares this kernel element for element with the oracle.
+//
+// One workgroup of 1024 threads per region.  Keys of all candidates (<= 32768: the grid of strotss_utils.py:89-97 never
+// has more) live in LDS (128 KB); the n-th smallest key is found by a three-level radix select (11 + 11 + 10 bits, LDS
+// histograms), ties at the threshold are taken in position order, the <= 1024 selected (key, candidate) pairs are sorted by
+// a bitonic network.  No global traffic besides the mask bytes and the 8 KB result.  Each wave owns a contiguous segment
+// of the candidate list (lane-consecutive addresses: conflict-free), positions under a mask come from ballots.
+#include "internal.h"
+
+namespace {
+
+constexpr int DRAW_T = 1024;
+constexpr int DRAW_MAXC = 32768;
+constexpr int DRAW_BINS = 2048;
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// exclusive prefix over the 16 waves' values (one value per wave, in lane 0..15 of wave 0 after the first barrier);
+// returns this wave's exclusive prefix, *total = sum.  `sh` holds >= 17 unsigned.
+__device__ __forceinline__ unsigned wave_totals_scan(unsigned wave_value, unsigned* sh, unsigned* total) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wv] = wave_value;
+  __syncthreads();
+  unsigned pre = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < DRAW_T / 64; ++i) {
+    const unsigned v = sh[i];
+    if (i < wv) pre += v;
+    tot += v;
+  }
+  *total = tot;
+  return pre;
+}
+
+__global__ __launch_bounds__(DRAW_T) void index_draw_kernel(strotss_draw_t d) {
+  __shared__ unsigned keys[DRAW_MAXC];
+  __shared__ unsigned vbits[DRAW_MAXC / 32];
+  __shared__ unsigned hist[DRAW_BINS];
+  __shared__ unsigned long long list[DRAW_T];
+  __shared__ unsigned sh[32];
+  const int r = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const unsigned t = d.counter[r];
+  const unsigned char* mask = d.mask[r];
+  unsigned o4[4];
+  philox4x32_10(0u, 1u, t, 0u, d.seed_lo, d.seed_hi, o4);
+  const int off_x = (int)(o4[0] % (unsigned)d.step_x);
+  philox4x32_10(1u, 1u, t, 0u, d.seed_lo, d.seed_hi, o4);
+  const int off_y = (int)(o4[0] % (unsigned)d.step_y);
+  const int nx = (d.h - off_x + d.step_x - 1) / d.step_x, ny = (d.w - off_y + d.step_y - 1) / d.step_y;
+  const int M = nx * ny;                                   // host guarantees <= DRAW_MAXC
+  // wave wv owns candidates [wv * seg, (wv + 1) * seg), seg a multiple of 64; lane l takes c = base + i * 64 + l
+  const int seg = ((M + DRAW_T - 1) / DRAW_T) * 64, trips = seg / 64;
+  const int c_begin = wv * seg;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int i = tid; i < DRAW_MAXC / 32; i += DRAW_T) vbits[i] = 0u;
+  // ---- validity (mask filter) and the position j of every valid candidate in the filtered list
+  unsigned wave_valid = 0;
+  if (mask) {
+    for (int i = 0; i < trips; ++i) {
+      const int c = c_begin + i * 64 + lane;
+      bool v = false;
+      if (c < M) {
+        const int x = off_x + (c % nx) * d.step_x, y = off_y + (c / nx) * d.step_y;
+        v = mask[(size_t)x * d.w + y] != 0;
+      }
+      wave_valid += (unsigned)__popcll(__ballot(v));
+    }
+  } else {
+    wave_valid = (unsigned)max(0, min(seg, M - c_begin));
+  }
+  unsigned Mv;
+  const unsigned wave_base = wave_totals_scan(wave_valid, sh, &Mv);       // (its barriers also cover the vbits clear)
+  const int n_out = (int)min((unsigned)d.sample_size, Mv);
+  if (n_out == 0) {                                                        // uniform: nothing survives the mask
+    if (tid == 0) { if (d.n_out) d.n_out[r] = 0; d.counter[r] = t + d.counter_stride; }
+    return;
+  }
+  // ---- keys: philox(j >> 2)[j & 3]
+  if (!mask) {
+    // positions = candidates: one generator call gives the keys of four consecutive candidates (seg % 4 == 0)
+    for (int q = c_begin / 4 + lane; q < (c_begin + seg) / 4; q += 64) {
+      if (q * 4 < M) {
+        philox4x32_10((unsigned)q, 0u, t, 0u, d.seed_lo, d.seed_hi, o4);
+        *reinterpret_cast<uint4*>(&keys[q * 4]) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+      }
+    }
+    for (int i = c_begin / 32 + lane; i < (c_begin + seg) / 32; i += 64) {
+      const int rem = M - i * 32;
+      vbits[i] = rem >= 32 ? 0xFFFFFFFFu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
+    }
+  } else {
+    unsigned running = wave_base;
+    for (int i = 0; i < trips; ++i) {
+      const int c = c_begin + i * 64 + lane;
+      bool v = false;
+      if (c < M) {
+        const int x = off_x + (c % nx) * d.step_x, y = off_y + (c / nx) * d.step_y;
+        v = mask[(size_t)x * d.w + y] != 0;
+      }
+      const unsigned long long b = __ballot(v);
+      if (v) {
+        const unsigned j = running + (unsigned)__popcll(b & lt_mask);
+        philox4x32_10(j >> 2, 0u, t, 0u, d.seed_lo, d.seed_hi, o4);
+        keys[c] = o4[j & 3];
+      }
+      if (lane == 0) { vbits[c >> 5] = (unsigned)b; vbits[(c >> 5) + 1] = (unsigned)(b >> 32); }
+      running += (unsigned)__popcll(b);
+    }
+  }
+  __syncthreads();
+  // ---- radix select: the key T of rank n_out (1-based) among the valid candidates
+  unsigned prefix = 0, pmask = 0, need = (unsigned)n_out;
+#pragma unroll
+  for (int level = 0; level < 3; ++level) {
+    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+    const unsigned nb = level == 2 ? 1024u : 2048u;
+    for (int i = tid; i < DRAW_BINS; i += DRAW_T) hist[i] = 0u;
+    __syncthreads();
+    for (int i = 0; i < trips; ++i) {
+      const int c = c_begin + i * 64 + lane;
+      if (c < M && ((vbits[c >> 5] >> (c & 31)) & 1u)) {
+        const unsigned k = keys[c];
+        if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & (nb - 1u)], 1u);
+      }
+    }
+    __syncthreads();
+    // thread owns bins 2*tid, 2*tid+1; inclusive scan over threads
+    const unsigned h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+    unsigned s = h0 + h1, incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    unsigned tot;
+    const unsigned wave_sum = __shfl(incl, 63, 64);
+    const unsigned wpre = wave_totals_scan(wave_sum, sh, &tot);
+    incl += wpre;
+    const unsigned excl = incl - s;
+    if (excl < need && need <= incl) {                                     // exactly one thread
+      const bool second = need > excl + h0;
+      sh[20] = (unsigned)(2 * tid + (second ? 1 : 0));
+      sh[21] = excl + (second ? h0 : 0u);
+    }
+    __syncthreads();
+    const unsigned bin = sh[20], before = sh[21];
+    need -= before;
+    prefix |= bin << shift;
+    pmask |= (nb - 1u) << shift;
+    __syncthreads();
+  }
+  const unsigned T = prefix, ties_needed = need;                           // candidates with key == T: the first `need` by position
+  // ---- ties at the threshold, in position order
+  unsigned wave_ties = 0;
+  for (int i = 0; i < trips; ++i) {
+    const int c = c_begin + i * 64 + lane;
+    const bool tie = c < M && ((vbits[c >> 5] >> (c & 31)) & 1u) && keys[c] == T;
+    wave_ties += (unsigned)__popcll(__ballot(tie));
+  }
+  unsigned all_ties;
+  unsigned tie_run = wave_totals_scan(wave_ties, sh, &all_ties);
+  if (tid == 0) sh[24] = 0u;
+  __syncthreads();
+  for (int i = 0; i < trips; ++i) {
+    const int c = c_begin + i * 64 + lane;
+    bool valid = c < M && ((vbits[c >> 5] >> (c & 31)) & 1u);
+    const unsigned k = valid ? keys[c] : 0u;
+    const bool tie = valid && k == T;
+    const unsigned long long b = __ballot(tie);
+    bool take = valid && k < T;
+    if (tie) take = tie_run + (unsigned)__popcll(b & lt_mask) < ties_needed;
+    tie_run += (unsigned)__popcll(b);
+    if (take) {
+      const unsigned slot = atomicAdd(&sh[24], 1u);
+      list[slot] = ((unsigned long long)k << 32) | (unsigned)c;
+    }
+  }
+  __syncthreads();
+  if (tid >= n_out) list[tid] = ~0ull;
+  __syncthreads();
+  // ---- bitonic sort of the 1024 slots, ascending by (key, candidate)
+  for (int k = 2; k <= DRAW_T; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int p = tid ^ j;
+      if (p > tid) {
+        const unsigned long long a = list[tid], b = list[p];
+        const bool up = (tid & k) == 0;
+        if ((a > b) == up) { list[tid] = b; list[p] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  float* out = d.idx[r];
+  if (tid < d.sample_size) {
+    float fx = 0.f, fy = 0.f;
+    if (tid < n_out) {
+      const int c = (int)(unsigned)(list[tid] & 0xFFFFFFFFull);
+      fx = (float)(off_x + (c % nx) * d.step_x);
+      fy = (float)(off_y + (c / nx) * d.step_y);
+    }
+    out[2 * tid] = fx; out[2 * tid + 1] = fy;
+  }
+  if (tid == 0) { if (d.n_out) d.n_out[r] = n_out; d.counter[r] = t + d.counter_stride; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int strotss_index_draw_max_candidates(int h, int w, int step_x, int step_y) {
+  if (h <= 0 || w <= 0 || step_x <= 0 || step_y <= 0) return STROTSS_EINVAL;
+  return ((h + step_x - 1) / step_x) * ((w + step_y - 1) / step_y);          // offsets 0, 0: the largest grid
+}
+
+int strotss_index_draw(const strotss_draw_t* d, void* stream) {
+  ST_CHECK_ARG(d && d->counter && d->h > 0 && d->w > 0 && d->step_x > 0 && d->step_y > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(d->n_regions > 0 && d->n_regions <= STROTSS_DRAW_MAX_REGIONS, STROTSS_EINVAL);
+  ST_CHECK_ARG(d->sample_size > 0 && d->sample_size <= DRAW_T, STROTSS_EINVAL);
+  ST_CHECK_ARG(strotss_index_draw_max_candidates(d->h, d->w, d->step_x, d->step_y) <= DRAW_MAXC, STROTSS_ERANGE);
+  for (int r = 0; r < d->n_regions; ++r) ST_CHECK_ARG(d->idx[r] != nullptr, STROTSS_EINVAL);
+  hipLaunchKernelGGL(index_draw_kernel, dim3((unsigned)d->n_regions), dim3(DRAW_T), 0, (hipStream_t)stream, *d);
+  ST_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STROTSS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libstrotss_hip.so")
 
 MAX_MAPS, MAX_DIVS, MAX_TENSORS = 12, 8, 8
-ABI_VERSION = 5          # must equal strotss_abi_version() of the loaded library (argument lists change with it)
+ABI_VERSION = 6          # must equal strotss_abi_version() of the loaded library (argument lists change with it)
 
 
 class StrotssHipError(RuntimeError):
@@ -33,6 +33,17 @@ class MapsT(C.Structure):
                 ("gmap", C.c_void_p * MAX_MAPS),
                 ("row0", C.c_int * MAX_MAPS), ("rows", C.c_int * MAX_MAPS),
                 ("window_drop", C.c_int), ("sample_range", C.c_void_p)]
+
+
+MAX_DRAW_REGIONS = 16
+
+
+class DrawT(C.Structure):
+    """strotss_draw_t (include/strotss_hip.h): the device-side draw of a step's sample coordinates"""
+    _fields_ = [("h", C.c_int), ("w", C.c_int), ("step_x", C.c_int), ("step_y", C.c_int), ("sample_size", C.c_int),
+                ("n_regions", C.c_int), ("seed_lo", C.c_uint), ("seed_hi", C.c_uint), ("counter_stride", C.c_uint),
+                ("mask", C.c_void_p * MAX_DRAW_REGIONS), ("idx", C.c_void_p * MAX_DRAW_REGIONS),
+                ("counter", C.c_void_p), ("n_out", C.c_void_p)]
 
 
 class PyramidT(C.Structure):
@@ -78,6 +89,10 @@ SIGNATURES = {
     "strotss_hypercol_scatter_plan_bytes": (_Z, [_I]),
     "strotss_hypercol_scatter_plan": (_I, [C.POINTER(MapsT), _P, _I, _P, _Z, _P]),
     "strotss_hypercol_scatter_sorted": (_I, [C.POINTER(MapsT), _P, _I, _P, _I, _I, _I, _I, _P]),
+    "strotss_calib_mfma": (_I, [_I, _I, _I, _P, _P, _P]),
+    "strotss_calib_copy": (_I, [_P, _P, _Z, _P]),
+    "strotss_index_draw_max_candidates": (_I, [_I, _I, _I, _I]),
+    "strotss_index_draw": (_I, [C.POINTER(DrawT), _P]),
     "strotss_row_inv_norm": (_I, [_P, _I, _I, _P, _P]),
     "strotss_cosine_distance": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _I, _P]),
     "strotss_l2_distance": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),

@@ -378,6 +378,56 @@ def hypercol_scatter_sorted(maps_t, plan: torch.Tensor, n: int, gfeat: torch.Ten
 
 
 # ------------------------------------------------------------------ losses
+def index_draw(h: int, w: int, sample_size: int, seed: int, counters: torch.Tensor, out_idx, masks=None, n_out=None,
+               stride=None) -> None:
+    """One launch of strotss_index_draw (csrc/draw.hip; reference: Sampling._make_indices, strotss_utils.py:83-121): region r's
+    next draw of its stream (draw number counters[r], advanced by `stride` afterwards) -> out_idx[r] (sample_size, 2) float32.
+    masks: per region a (h, w) uint8 device tensor at THIS scale (nonzero = keep) or None; n_out: int32 (R,) or None.
+    nn/rand.py:PhiloxStream(seed, t) is the host twin of draw number t."""
+    from .strotss_utils import sampling_steps
+    R = len(out_idx)
+    assert 0 < R <= _hip.MAX_DRAW_REGIONS and counters.dtype == torch.int32 and counters.numel() >= R and counters.is_cuda
+    d = _hip.DrawT()
+    d.h, d.w = int(h), int(w)
+    d.step_x, d.step_y = sampling_steps(int(h), int(w))
+    d.sample_size, d.n_regions = int(sample_size), R
+    d.seed_lo, d.seed_hi = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
+    d.counter_stride = R if stride is None else int(stride)
+    for r in range(R):
+        o = out_idx[r]
+        assert o.is_cuda and o.dtype == torch.float32 and o.is_contiguous() and o.numel() >= 2 * sample_size
+        d.idx[r] = o.data_ptr()
+        m = None if masks is None else masks[r]
+        if m is not None:
+            assert m.is_cuda and m.dtype == torch.uint8 and m.is_contiguous() and tuple(m.shape) == (int(h), int(w))
+            d.mask[r] = m.data_ptr()
+    d.counter = counters.data_ptr()
+    if n_out is not None:
+        assert n_out.dtype == torch.int32 and n_out.numel() >= R and n_out.is_cuda
+        d.n_out = n_out.data_ptr()
+    check(_hip.lib().strotss_index_draw(C.byref(d), stream_ptr()), "index_draw")
+
+
+def index_draw_counts(h: int, w: int, masks=None):
+    """(max candidates of the grid, min over all offset pairs and regions of the number of candidates that survive the
+    mask): what decides whether a scale can draw on the device with a fixed sample count.  masks: boolean (h, w) host arrays
+    or None.  Pure host arithmetic."""
+    import numpy as np
+    from .strotss_utils import sampling_steps
+    sx, sy = sampling_steps(int(h), int(w))
+    most = -(-h // sx) * -(-w // sy)
+    least = None
+    for ox in range(sx):
+        for oy in range(sy):
+            if masks is None or all(m is None for m in masks):
+                cnt = len(range(ox, h, sx)) * len(range(oy, w, sy))
+            else:
+                cnt = min(int(np.asarray(m)[ox::sx, oy::sy].sum()) if m is not None else
+                          len(range(ox, h, sx)) * len(range(oy, w, sy)) for m in masks)
+            least = cnt if least is None else min(least, cnt)
+    return most, least
+
+
 class _WsCache:
     """Grow-only workspace per (device, tag): the C ABI never allocates.  Growth REALLOCATES, which a captured hipGraph
     must never see (the graph holds the old pointer): StepEngine.capture_graph therefore runs one full eager step on a

@@ -203,9 +203,11 @@ class StepEngine:
             raise _hip.StrotssHipError("strotss_debug_winograd_stages was left at a partial mask (a timing pass did not "
                                        "restore it): results since then are meaningless")
         self.steps_done = 0
+        self._draw = None                 # device-side index draw (enable_device_draw): counters, masks, output buffers
         self._graph = None
         self._graph_post = None           # sharded regions: the part of the step after the all-reduce
         self._strip_graphs = None         # image strips: the three stages between the two all-reduces
+        self._graph_drawn = False         # the captured graph starts with the draw kernel (no per-step upload)
         self._graph_idx: List[torch.Tensor] = []
         self._graph_n: List[int] = []
 
@@ -382,11 +384,57 @@ class StepEngine:
         self.gimg_full[:, :self.strips.win0].zero_()
         self.gimg_full[:, self.strips.win1:].zero_()
 
+    # ---- the step's sample coordinates drawn on the device (csrc/draw.hip), inside the step and inside its graph
+    def enable_device_draw(self, seed: int, t0: int = 0, masks: Optional[Sequence] = None) -> bool:
+        """Draw every step's index sets on the device (reference: Sampling._make_indices inside the traced train_step,
+        strotss_utils.py:83-121 / run_strotss.py:136, 115): region r of step s uses draw number t0 + s*R + r of the Philox
+        stream with key `seed` -- what `make_indices_np(..., rng=rand.PhiloxStream(seed, t0))` called region by region, step
+        by step, returns on the host.  masks: per region a boolean (h, w) host array at this scale, or None.
+        Returns False (and changes nothing) where the device draw does not apply: image strips (the host orders every set
+        by owning rank), a grid of more than 32768 candidates, or a region that an unlucky offset leaves with fewer
+        candidates than samples (the sample count must be the same at every step: it shapes the launches)."""
+        if self.strips is not None:
+            return False
+        masks = list(masks) if masks is not None else [None] * self.R
+        assert len(masks) == self.R
+        most, least = _ops.index_draw_counts(self.h, self.w, masks)
+        if most > 32768 or least < self.sample_size or self.R > _hip.MAX_DRAW_REGIONS or self.sample_size > 1024:
+            return False
+        dev = self.variables[0].device
+        counters = torch.tensor([int(t0) + r for r in range(self.R)], dtype=torch.int64).to(torch.int32).to(dev)
+        mask_dev = [None if m is None else torch.from_numpy(np.ascontiguousarray(m, dtype=np.uint8)).to(dev) for m in masks]
+        idx = [torch.zeros((self.sample_size, 2), dtype=torch.float32, device=dev) for _ in range(self.R)]
+        self._draw = dict(seed=int(seed), t0=int(t0), counters=counters, masks=mask_dev, idx=idx)
+        return True
+
+    def draws_done(self) -> int:
+        """draws consumed so far by the device stream (to advance the host twin: rand.PhiloxStream.skip)"""
+        return 0 if self._draw is None else self.steps_done * self.R
+
+    def _draw_indices(self) -> List[torch.Tensor]:
+        dr = self._draw
+        _ops.index_draw(self.h, self.w, self.sample_size, dr["seed"], dr["counters"], dr["idx"], dr["masks"])
+        return dr["idx"]
+
     def apply_gradients(self) -> None:
         """opt.apply_gradients (run_strotss.py:148): Keras RMSprop, all 6 tensors in one launch."""
         _ops.rmsprop_step(self.variables, self.rms, self.gvars, self.lr, self.rho, self.eps)
 
-    def step(self, indices: Sequence[torch.Tensor], strip_offsets: Optional[Sequence[int]] = None) -> None:
+    def step(self, indices: Optional[Sequence[torch.Tensor]] = None, strip_offsets: Optional[Sequence[int]] = None) -> None:
+        """One optimisation step.  indices None: the index sets are drawn on the device at the head of the step
+        (enable_device_draw first); otherwise they are the caller's (injected: tests, fixtures, strips)."""
+        if indices is None:
+            assert self._draw is not None, "step() without indices needs enable_device_draw()"
+            if self._graph is not None and self._graph_drawn:
+                self._graph.replay()
+                if self._graph_post is not None:
+                    self._reduce()
+                    self._graph_post.replay()
+            else:
+                self.forward_backward(self._draw_indices())
+                self.apply_gradients()
+            self.steps_done += 1
+            return
         if self.strips is not None:
             if self._strip_graphs is not None and all(int(i.shape[0]) == self._graph_n[r] for r, i in enumerate(indices)):
                 for dst, src in zip(self._graph_idx, indices):
@@ -403,7 +451,7 @@ class StepEngine:
                 self.apply_gradients()
             self.steps_done += 1
             return
-        if self._graph is not None and all(int(i.shape[0]) == self._graph_n[r] for r, i in enumerate(indices)):
+        if self._graph is not None and not self._graph_drawn and all(int(i.shape[0]) == self._graph_n[r] for r, i in enumerate(indices)):
             for dst, src in zip(self._graph_idx, indices):
                 dst.copy_(src, non_blocking=True)
             self._graph.replay()
@@ -415,7 +463,7 @@ class StepEngine:
             self.apply_gradients()
         self.steps_done += 1
 
-    def capture_graph(self, example_indices: Sequence[torch.Tensor], example_offsets=None) -> None:
+    def capture_graph(self, example_indices: Optional[Sequence[torch.Tensor]] = None, example_offsets=None) -> None:
         """Capture forward_backward + apply_gradients into ONE hipGraph (the ~100 launches of a step
         replay as one submission; the 64-256 px scales are otherwise bound by host launch rate).  Index
         sets are copied into static buffers before each replay; a step whose index counts differ from
@@ -431,13 +479,22 @@ class StepEngine:
             if self._halo is None and example_offsets is not None:
                 self._capture_strip_graphs(example_indices, example_offsets)
             return
-        snap = [t.clone() for t in self.variables + self.rms]
-        self._graph_idx = [i.clone() for i in example_indices]
-        self._graph_n = [int(i.shape[0]) for i in example_indices]
+        drawn = example_indices is None        # the draw kernel is the first node of the graph: nothing to upload per step
+        state = self.variables + self.rms
+        if drawn:
+            assert self._draw is not None, "capture_graph() without indices needs enable_device_draw()"
+            state = state + [self._draw["counters"]]       # warm-up and capture passes draw too: put the counters back
+            self._graph_idx = self._draw["idx"]
+            self._graph_n = [self.sample_size] * self.R
+        else:
+            self._graph_idx = [i.clone() for i in example_indices]
+            self._graph_n = [int(i.shape[0]) for i in example_indices]
+        snap = [t.clone() for t in state]
+        head = (lambda: self._pixel_gradient(self._draw_indices())) if drawn else (lambda: self._pixel_gradient(self._graph_idx))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):              # warm-up on the side stream (workspace allocation)
-            self._pixel_gradient(self._graph_idx)
+            head()
             self._fold_adjoint()
             self.apply_gradients()
         torch.cuda.current_stream().wait_stream(side)
@@ -445,19 +502,19 @@ class StepEngine:
         g, post = torch.cuda.CUDAGraph(), None
         if self.sharded:
             with _Capture(g, side):
-                self._pixel_gradient(self._graph_idx)
+                head()
             post = torch.cuda.CUDAGraph()
             with _Capture(post, side):
                 self._fold_adjoint()
                 self.apply_gradients()
         else:
             with _Capture(g, side):
-                self._pixel_gradient(self._graph_idx)
+                head()
                 self._fold_adjoint()
                 self.apply_gradients()
-        for t, s0 in zip(self.variables + self.rms, snap):
+        for t, s0 in zip(state, snap):
             t.copy_(s0)
-        self._graph, self._graph_post = g, post
+        self._graph, self._graph_post, self._graph_drawn = g, post, drawn
 
     # ------------------------------------------------------------------ read-outs (host sync)
     def _capture_strip_graphs(self, example_indices, example_offsets) -> None:

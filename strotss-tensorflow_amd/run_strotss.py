@@ -103,6 +103,25 @@ def _optimise_scale(eng, scl: int, content_masks, args, dev, quiet: bool = False
     # memory would block the host until the previous step has drained, leaving the GPU idle while the next draw is
     # computed (~0.3 ms per step, a quarter of a 64-px step): a small ring of pinned buffers + asynchronous copies lets
     # the host draw step k+1 while the GPU runs step k.
+    # Round 4: the draw itself runs on the device, as the first kernel of the captured step (csrc/draw.hip; counter-based
+    # Philox stream whose host twin is rand.index_rng, so the sequence is the one the host loop below would draw) -- wherever
+    # the sample count cannot vary from step to step.  No upload, no ring, nothing for the host to do per step.
+    stream = rand.index_rng
+    if (dev.type == "cuda" and not getattr(args, "host_draw", False) and isinstance(stream, rand.PhiloxStream)
+            and eng.enable_device_draw(stream.seed, stream.t, masks_here)):
+        with tqdm(range(args.max_iter), disable=quiet) as bar:
+            for it in bar:
+                if it == 0 and not getattr(args, "no_graph", False):
+                    eng.capture_graph()
+                eng.step()
+                if step_trace is not None:
+                    step_trace.append(eng.losses())
+                if (it + 1) % log_every == 0 or it + 1 == args.max_iter:
+                    r = eng.losses()
+                    bar.set_description(f"Scale: {scl:4d} - It: {it+1:4d}")
+                    bar.set_postfix({k: f'{r[k]:.3f}' for k in ('loss', 'loss_c', 'loss_s')})
+        stream.skip(args.max_iter * len(masks_here))          # the host twin moves past the draws the device made
+        return
     ring, slots = 8, {}
     with tqdm(range(args.max_iter), disable=quiet) as bar:
         for it in bar:
@@ -214,6 +233,8 @@ _FLAGS = (
     (("--start_level",), dict(type=int, default=0)), (("--seed",), dict(type=int, default=0)),
     (("--weights",), dict(type=str, default=None)), (("--log_every",), dict(type=int, default=10)),
     (("--no_graph",), dict(action='store_true', help="eager kernel launches instead of one hipGraph per step")),
+    (("--host_draw",), dict(action='store_true', help="draw the sample coordinates on the host every step (the same sequence; "
+                                                      "the default draws them on the device inside the step)")),
     (("--strips",), dict(action='store_true', help="under torchrun: shard ONE image over the GPUs by image strips")),
     (("--halo",), dict(action='store_true', help="with --strips: per-layer halo EXCHANGE with the neighbouring ranks (16-row "
                                                  "windows margins, one row per layer and direction) instead of a 128-row recompute margin")),

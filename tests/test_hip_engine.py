@@ -458,6 +458,7 @@ def test_run_schedule_matches_oracle_run_scales(tmp_path, start_level):
     import run_strotss as RS
     from nn import utils
     from nn.model import synthetic_weights
+    from nn.rand import PhiloxStream
     cpath, spath = _write_pair(tmp_path)
     args = RS.build_parser().parse_args([cpath, spath, "-o", str(tmp_path / "o.jpg"), "--level", "3", "--max_iter", "2",
                                          "--log_every", "1", "--start_level", str(start_level), "--seed", "5"])
@@ -471,7 +472,7 @@ def test_run_schedule_matches_oracle_run_scales(tmp_path, start_level):
     otr, osteps = [], []
     O.run_scales(content, style, synthetic_weights('16', 5), level=3, start_level=start_level, max_iter=2, lr=2e-3,
                  alpha=1.0, seed=5, sample_size=1024, dtype=torch.float64, scale_trace=otr, trace=osteps,
-                 previous_override=lambda i: finals.get(i - 1))
+                 previous_override=lambda i: finals.get(i - 1), rng=PhiloxStream(5))   # the product's stream: its host twin
     assert len(otr) == n_scales
     for t, o in zip(tr, otr):
         assert (t["i"], t["scl"]) == (o["i"], o["scl"])

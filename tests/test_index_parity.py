@@ -77,3 +77,112 @@ def test_sampling_make_indices_equals_oracle_with_gpu_resized_mask(h, w, bilinea
         assert got.dtype == np.float32 and got.shape == ref.shape and np.array_equal(got, ref), name
     got = SU.Sampling(1024, rng=np.random.default_rng(2))._make_indices(base, bilinear).cpu().numpy()
     assert np.array_equal(got, O.make_indices(h, w, bilinear, 1024, np.random.default_rng(2)))
+
+
+# ------------------------------------------------------------------ round 4: the counter-based stream and the device-side draw
+from nn import rand as RAND                      # noqa: E402
+
+
+def test_philox_known_answers_and_host_twin_against_the_oracle():
+    """Philox4x32-10 known-answer vectors (Random123 kat_vectors), and the product's host draw == the oracle's draw when both
+    consume the product's stream object (PhiloxStream: `integers` / `permutation`, one draw number per make_indices call)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in RAND.philox4x32_10(*ctr, *key)) == want
+    a, b = RAND.PhiloxStream(9), RAND.PhiloxStream(9)
+    for h, w in [(64, 64), (170, 256), (683, 1024)]:
+        for bilinear in (True, False):
+            if h * w > 300000 and not bilinear:
+                continue
+            x = SU.make_indices_np(h, w, bilinear, 1024, a)
+            y = O.make_indices(h, w, bilinear, 1024, b)
+            assert np.array_equal(x, y) and a.t == b.t
+    assert a.t == 5                                                        # one draw number per call
+    # a permutation of every position, ties impossible to observe here but the order is total: (key, position)
+    p = RAND.PhiloxStream(1, 7).permutation(5000)
+    assert np.array_equal(np.sort(p), np.arange(5000))
+    k = RAND.PhiloxStream(1, 7).keys(5000)
+    assert np.all(np.diff(k[p].astype(np.int64)) >= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", [(64, 64), (128, 96), (170, 256), (683, 1024), (1024, 1024), (181, 181), (42, 64)])
+def test_device_index_draw_equals_the_oracle_draw_element_for_element(h, w):
+    """strotss_index_draw (csrc/draw.hip) against O.make_indices fed with the stream's host twin: offsets, strided grid in
+    meshgrid('xy') order, mask filter (the mask resized and thresholded by the HIP kernel), shuffle, first n -- bit for bit,
+    for consecutive draws (the kernel advances its own counters), several regions in one launch, two sample sizes; (683, 1024)
+    has 16758 candidates, (181, 181) 32761: the kernel's limit is 32768."""
+    from nn import _ops
+    masks = _masks(h, w)
+    keep = {k: SU.mask_at_scale(torch.from_numpy(m), h, w) for k, m in masks.items()}
+    for k in keep:
+        assert np.array_equal(keep[k], _oracle_keep(masks[k], h, w))
+    regions = [None, "half", "blobs"]
+    dev_masks = [None if k is None else torch.from_numpy(keep[k].astype(np.uint8)).cuda() for k in regions]
+    most, least = _ops.index_draw_counts(h, w, [None if k is None else keep[k] for k in regions])
+    assert most <= 32768 and 0 <= least <= most       # (regions with fewer candidates than samples return fewer coordinates)
+    for n, seed, t0 in ((1024, 0, 0), (256, 0x1234567890, 41)):
+        R = len(regions)
+        counters = torch.tensor([t0 + r for r in range(R)], dtype=torch.int32, device="cuda")
+        n_out = torch.full((R,), -1, dtype=torch.int32, device="cuda")
+        out = [torch.full((n, 2), -7.0, device="cuda") for _ in range(R)]
+        twin = RAND.PhiloxStream(seed, t0)
+        for step in range(3):
+            _ops.index_draw(h, w, n, seed, counters, out, dev_masks, n_out)
+            torch.cuda.synchronize()
+            assert counters.tolist() == [t0 + (step + 1) * R + r for r in range(R)]
+            for r, k in enumerate(regions):
+                assert twin.t == t0 + step * R + r
+                ref = O.make_indices(h, w, True, n, twin, mask=None if k is None else masks[k])
+                got = out[r].cpu().numpy()
+                cnt = int(n_out[r])
+                assert cnt == ref.shape[0], (k, cnt, ref.shape)
+                assert np.array_equal(got[:cnt], ref), (h, w, n, step, k)
+                assert not got[cnt:].any()
+    # an empty mask region (nothing kept) returns zero coordinates and still advances its counter
+    none = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    counters = torch.tensor([5], dtype=torch.int32, device="cuda")
+    n_out = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    _ops.index_draw(h, w, 1024, 3, counters, [torch.zeros((1024, 2), device="cuda")], [none], n_out)
+    torch.cuda.synchronize()
+    assert int(n_out[0]) == 0 and int(counters[0]) == 6
+
+
+@pytest.mark.gpu
+def test_engine_device_draw_steps_equal_injected_host_draws():
+    """StepEngine.step() with the draw kernel at its head (eager and replayed from a graph whose first node it is) ==
+    StepEngine.step(indices) with the host twin's draws injected: the same index sets, hence (deterministic tap adjoint) the
+    same bits after three steps; the host twin advanced by draws_done() continues the same stream."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _region_worker as W
+    dev = torch.device("cuda", 0)
+    res = {}
+    for mode in ("host", "device_eager", "device_graph"):
+        eng, _ = W.problem(dev, None)                    # 3 mask regions (vertical bands), 96 x 128, 256 samples each
+        h, w, R = eng.h, eng.w, eng.R
+        edges = [round(r * w / R) for r in range(R + 1)]
+        masks = []
+        for a, b in zip(edges, edges[1:]):
+            m = np.zeros((h, w), dtype=bool); m[:, a:b] = True
+            masks.append(m)
+        twin = RAND.PhiloxStream(11, 100)
+        if mode == "host":
+            for _ in range(3):
+                eng.step([torch.from_numpy(SU.make_indices_np(h, w, True, eng.sample_size, twin, m)).to(dev) for m in masks])
+        else:
+            assert eng.enable_device_draw(11, 100, masks)
+            if mode == "device_graph":
+                eng.capture_graph()
+                assert eng._graph is not None and eng._graph_drawn
+            for _ in range(3):
+                eng.step()
+            assert eng.draws_done() == 9
+            assert eng._draw["counters"].tolist() == [100 + 9 + r for r in range(R)]
+        torch.cuda.synchronize()
+        res[mode] = ([v.clone() for v in eng.variables], eng.losses())
+    for mode in ("device_eager", "device_graph"):
+        assert res[mode][1] == res["host"][1], (mode, res[mode][1], res["host"][1])
+        assert all(torch.equal(a, b) for a, b in zip(res[mode][0], res["host"][0])), mode

@@ -107,17 +107,12 @@ def trajectory_inputs():
     return cfg, img(h, w, 41), img(h, w, 42)
 
 
-def trajectory_fixture():
-    """200 free-running RMSprop steps of ONE 64-px scale in float64 (run_strotss.py:131-155: train_step + apply_gradients,
-    first-scale initialisation and alpha, N = 1024 samples of the 4096 candidates, a fresh index set per step from one
-    seeded stream, seeded synthetic VGG16): the loss curve and the final image the HIP engine is compared with
-    (tests/test_golden_gpu.py::test_200_step_trajectory_against_the_float64_oracle).  The index sets are not stored: the
-    product's own draw (nn.strotss_utils.make_indices_np) is bit-equal to the oracle's (tests/test_index_parity.py); their
-    checksum is."""
+def _trajectory(dtype, init_noise=0.0):
     cfg, content, style = trajectory_inputs()
     h, w, n, steps = cfg["h"], cfg["w"], cfg["n_samples"], cfg["steps"]
     weights = O.make_synthetic_vgg16_weights(0)
-    vgg = O.VGG(weights, dtype=torch.float64)
+    vgg = O.VGG(weights, dtype=dtype)
+    content, style = content.to(dtype), style.to(dtype)
     rng = np.random.default_rng(cfg["seed"])
     s_idx = O.make_indices(h, w, False, n, rng)
     with torch.no_grad():
@@ -125,7 +120,10 @@ def trajectory_fixture():
         sf = [style] + vgg(style)
         ss = O.sample_features(sf, s_idx, False)
     init = O.make_laplacian(content) + style.mean(dim=(1, 2), keepdim=True)
-    variables = [v.clone().requires_grad_(True) for v in O.make_laplacian_pyramid(init)]
+    start = init
+    if init_noise:
+        start = init + init_noise * torch.randn(init.shape, generator=torch.Generator().manual_seed(99), dtype=torch.float64).to(dtype)
+    variables = [v.clone().requires_grad_(True) for v in O.make_laplacian_pyramid(start)]
     rms = [torch.zeros_like(v) for v in variables]
     trace, idx_sum = [], 0.0
     import time
@@ -138,13 +136,32 @@ def trajectory_fixture():
             for v, r, g in zip(variables, rms, res["grads"]):
                 O.rmsprop_update(v, r, g, cfg["lr"])
         trace.append([float(res["loss"]), float(res["loss_c"]), float(res["loss_s"])])
-        if it % 20 == 0:
-            print(f"trajectory step {it}: loss {trace[-1][0]:.5f}  ({time.time() - t0:.0f} s)", flush=True)
+        if it % 50 == 0:
+            print(f"trajectory {dtype} step {it}: loss {trace[-1][0]:.5f}  ({time.time() - t0:.0f} s)", flush=True)
     final = O.fold_laplacian_pyramid([v.detach() for v in variables])
-    np.savez_compressed(os.path.join(HERE, "trajectory_64px_200.npz"), trace=np.array(trace), final=final.numpy().astype(np.float32),
-                        final_u8=O.postprocess(final), style_idx_sum=float(s_idx.astype(np.float64).sum()), idx_checksum=idx_sum,
-                        init_u8=O.postprocess(init),
-                        weight_checksum=float(sum(float(w_.double().sum() + b.double().sum()) for w_, b in weights)))
+    return dict(trace=np.array(trace), final=final, s_idx=s_idx, idx_sum=idx_sum, init=init, weights=weights)
+
+
+def trajectory_fixture():
+    """200 free-running RMSprop steps of ONE 64-px scale (run_strotss.py:131-155: train_step + apply_gradients, first-scale
+    initialisation and alpha, N = 1024 samples of the 4096 candidates, a fresh index set per step from one seeded stream,
+    seeded synthetic VGG16) THREE times: in float64 (the trajectory the HIP engine is compared with,
+    tests/test_golden_gpu.py::test_200_step_trajectory_against_the_float64_oracle), in float32 (the same restatement in the
+    product's precision) and in float64 from a start image perturbed by 1e-7 -- the last two are the YARDSTICK: how far two
+    correct runs of this optimisation drift apart (RMSprop's first update is 10*lr*sign(g); the L1 / hard-min losses flip
+    signs and arg-mins), i.e. the tolerance a free-running comparison can state at all.  The index sets are not stored: the
+    product's own draw (nn.strotss_utils.make_indices_np) is bit-equal to the oracle's (tests/test_index_parity.py); their
+    checksum is."""
+    r64 = _trajectory(torch.float64)
+    r32 = _trajectory(torch.float32)
+    rpt = _trajectory(torch.float64, init_noise=1e-7)
+    np.savez_compressed(os.path.join(HERE, "trajectory_64px_200.npz"), trace=r64["trace"],
+                        final=r64["final"].numpy().astype(np.float32), final_u8=O.postprocess(r64["final"]),
+                        trace_f32=r32["trace"], final_u8_f32=O.postprocess(r32["final"]),
+                        trace_perturbed=rpt["trace"], final_u8_perturbed=O.postprocess(rpt["final"]),
+                        style_idx_sum=float(r64["s_idx"].astype(np.float64).sum()), idx_checksum=r64["idx_sum"],
+                        init_u8=O.postprocess(r64["init"]),
+                        weight_checksum=float(sum(float(w_.double().sum() + b.double().sum()) for w_, b in r64["weights"])))
 
 
 def image_fixture():

@@ -93,9 +93,12 @@ def test_200_step_trajectory_against_the_float64_oracle():
     re-synchronisation) on the HIP engine -- deterministic tap adjoint, the same seeded index stream, seeded weights --
     against the float64 oracle's trajectory committed in tests/golden/trajectory_64px_200.npz (generator:
     make_golden.py --trajectory-only; reference loop: run_strotss.py:131-155).  Bit equality is out of reach (RMSprop's first
-    update is 10*lr*sign(g), the L1 / hard-min losses flip signs and arg-mins on f32 rounding); what is asserted is what
-    DESIGN.md 6 states as the tolerance: the loss curve within LOSS_TOL of the oracle's at every step from step 20 on, and
-    the final uint8 image at PSNR >= PSNR_MIN dB of the oracle's."""
+    update is 10*lr*sign(g), the L1 / hard-min losses flip signs and arg-mins on f32 rounding): the fixture therefore also
+    holds two YARDSTICK runs of the oracle itself (float32; float64 from a start image perturbed by 1e-7), which drift from the
+    float64 run by 4 % of the loss per step on average, up to 13-16 % at single steps, 0.3 % in the mean loss of the last 50
+    steps and 26.7-27.5 dB PSNR of the final image.  What is asserted is the tolerance DESIGN.md 6 states: last-50-step mean
+    loss within 1.5 % of the oracle's, per-step deviations within 2.5x the yardsticks', final uint8 image no more than 2 dB
+    below the yardsticks' PSNR (measured on MI355X: 4.3 % / 21.8 % / 27.5 dB)."""
     from nn import _ops, engine, strotss_utils as SU
     from nn.model import VGGParams, synthetic_weights
     z = np.load(os.path.join(G, "trajectory_64px_200.npz"))
@@ -129,15 +132,25 @@ def test_200_step_trajectory_against_the_float64_oracle():
         trace.append([got["loss"], got["loss_c"], got["loss_s"]])
     assert idx_sum == float(z["idx_checksum"])                     # the same 200 index sets as the oracle's run
     trace, ref = np.array(trace), z["trace"]
-    rel = np.abs(trace[:, 0] - ref[:, 0]) / np.abs(ref[:, 0])
-    u8 = SU.postprocess(eng.stylized()).cpu().numpy().astype(np.float64)
-    mse = float(((u8 - z["final_u8"].astype(np.float64)) ** 2).mean())
-    psnr = 10.0 * np.log10(255.0 ** 2 / max(mse, 1e-12))
-    mean_abs = float(np.abs(eng.stylized().cpu().numpy() - z["final"]).mean())
-    print(f"TRAJECTORY 200 steps @64px: loss rel err max(first 20) {rel[:20].max():.3e}, max(20..) {rel[20:].max():.3e}, "
-          f"mean {rel.mean():.3e}, final loss {trace[-1, 0]:.6f} vs {ref[-1, 0]:.6f}; final image PSNR {psnr:.2f} dB, "
-          f"mean |d| {mean_abs:.5f}, bytes differing {int((u8 != z['final_u8']).sum())} of {u8.size}")
-    LOSS_TOL, PSNR_MIN = 2e-2, 30.0
-    assert rel[:20].max() < 5e-2, rel[:20].max()                   # the sign-like first updates
-    assert rel[20:].max() < LOSS_TOL, (int(rel[20:].argmax()) + 20, rel[20:].max())
-    assert psnr >= PSNR_MIN, psnr
+
+    def drift(tr, u8):
+        """how far a trajectory is from the float64 one: per-step relative loss error, the mean loss of the last 50 steps
+        (every step's loss is evaluated on its own random sample set: the windowed mean is the stable statistic), PSNR of the
+        final uint8 image"""
+        rel = np.abs(tr[:, 0] - ref[:, 0]) / np.abs(ref[:, 0])
+        mse = float(((u8.astype(np.float64) - z["final_u8"].astype(np.float64)) ** 2).mean())
+        return dict(max_head=float(rel[:20].max()), max_tail=float(rel[20:].max()), mean=float(rel.mean()),
+                    window=float(tr[150:, 0].mean() / ref[150:, 0].mean() - 1.0), psnr=float(10.0 * np.log10(255.0 ** 2 / max(mse, 1e-12))))
+    got = drift(trace, SU.postprocess(eng.stylized()).cpu().numpy())
+    # the YARDSTICK, from the same fixture: the float32 run of the oracle itself and its float64 run from a start image
+    # perturbed by 1e-7 -- two CORRECT runs of this optimisation drift this far apart (sign(g) first updates, L1 / hard-min
+    # flips), so no free-running comparison can state a tighter tolerance than a small multiple of these
+    y32, ypt = drift(z["trace_f32"], z["final_u8_f32"]), drift(z["trace_perturbed"], z["final_u8_perturbed"])
+    print("TRAJECTORY 200 steps @64px  (max |rel loss| steps <20 / >=20, mean |rel|, last-50-step mean loss vs oracle, PSNR of the final uint8 image)")
+    for name, d in (("HIP engine", got), ("oracle float32", y32), ("oracle float64, start + 1e-7", ypt)):
+        print(f"  {name:30s} {d['max_head']:.3f} / {d['max_tail']:.3f}   {d['mean']:.4f}   {100 * d['window']:+.2f} %   {d['psnr']:.2f} dB")
+    worst = {k: max(abs(y32[k]), abs(ypt[k])) for k in ("max_head", "max_tail", "mean", "window")}
+    # the stated tolerance (DESIGN.md 6): the stable statistics tight, the per-step ones within 2.5x what correct runs show
+    assert abs(got["window"]) < 0.015, got                     # yardsticks: 0.24 % and 0.29 %
+    assert got["mean"] < 2.5 * worst["mean"] and got["max_tail"] < 2.5 * worst["max_tail"] and got["max_head"] < 2.5 * worst["max_head"], (got, worst)
+    assert got["psnr"] >= min(y32["psnr"], ypt["psnr"]) - 2.0, (got["psnr"], y32["psnr"], ypt["psnr"])

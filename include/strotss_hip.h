@@ -297,6 +297,15 @@ int strotss_l2_distance(const float* x, int nx, const float* y, int ny, int d, i
 int strotss_row_inv_norm_x3(const float* x, int n, int ld, float* r, void* panels, void* stream);
 int strotss_cosine_distance_x3(const void* x_panels, const float* rx, int nx, const void* y_panels, const float* ry,
                                int ny, int ld, float* C, int ldc, void* stream);
+/* Backward of a pairwise distance matrix w.r.t. one of its row sets (what tape.gradient does to nn/losses.py:12-24):
+ *   dx[i, :] += g * r[i] * ( sum_{j < k} W[i, j] * B[j, :]  -  x[i, :] * r[i] * q[i] ),   i < n,
+ * W (n rows, ldw >= k floats per row, ldw % 32 == 0, entries j >= k zero), B (>= ldw rows of ld floats, rows >= k zero or
+ * finite), x / dx (n, ld), ld % 32 == 0; r, q: n floats.  cosine_distance(x, y) with upstream gradient G: W = -G * ry[j],
+ * B = y, r = the reciprocal norms of x, q[i] = -sum_j G[i, j] (1 - C[i, j]);  l2_distance: W = -2 G' (G' = G / (2 D C) where
+ * the clamp passes), B = y, r = 1, q[i] = -2 sum_j G'[i, j].  f32 MFMA (the loss path's own backward GEMMs run on the
+ * bf16x3 core from pre-split panels; this entry is the operator surface's). */
+int strotss_rows_gemm_bwd(const float* W, int ldw, int k, const float* B, const float* x, const float* r, const float* q,
+                          int n, int ld, float g, float* dx, void* stream);
 size_t strotss_selfsim_workspace_bytes(int n, int ld);
 /* loss_out[0] = self_similarity(pred, content) (losses.py:55-66);
  * gpred += gscale * dloss/dpred.  pred/content: (rows >= n, ld). */
@@ -318,8 +327,12 @@ int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, co
 size_t strotss_remd_workspace_bytes(int ns, int n, int ld);
 /* loss_out[0] = relaxed_emd(style, pred, 'cosine') (losses.py:69-80); gpred += gscale*dloss/dpred.
  * rs = row_inv_norm(style) (constant per scale). */
+/* flags (this entry, strotss_remd_metric_fwd_bwd, strotss_palette_remd_fwd_bwd): STROTSS_REMD_SWAPPED = the caller wants the
+ * gradient w.r.t. the reference's FIRST argument x and therefore passed x as `pred` and y as `style` (every metric is symmetric,
+ * the value is the same); tf.maximum(R_X, R_Y) sends an exact tie to R_X, which is then the kernel's column branch. */
+#define STROTSS_REMD_SWAPPED 1
 int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n,
-                             int d, int ld, float gscale, float* gpred, float* loss_out,
+                             int d, int ld, float gscale, float* gpred, float* loss_out, int flags,
                              void* workspace, size_t workspace_bytes, void* stream);
 /* The same with its prologue already done (a train step computes the prediction rows' reciprocal norms and x3 panels for
  * the content loss anyway, and the style rows' panels do not change within a scale): pred_inv_norm / pred_panels as
@@ -339,7 +352,7 @@ int strotss_remd_cos_fwd_bwd_panels(const float* style, const float* rs, const v
  * (strotss_utils.py:166-167) to them first; 0 takes them as they are (losses.relaxed_emd 'both').
  * Workspace: strotss_remd_workspace_bytes(ns, n, 0). */
 int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld,
-                                 int rgb_to_yuv, float gscale, float* gpred, float* loss_out,
+                                 int rgb_to_yuv, float gscale, float* gpred, float* loss_out, int flags,
                                  void* workspace, size_t workspace_bytes, void* stream);
 /* relaxed_emd(style, pred, distance) for the other two entries of dist_metrics (losses.py:27-28) at ANY width d:
  * metric STROTSS_METRIC_L2 -> l2_distance (losses.py:18-24), STROTSS_METRIC_BOTH -> cosine + l2.  Same reductions and
@@ -349,7 +362,7 @@ int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, 
 #define STROTSS_METRIC_BOTH 2
 size_t strotss_remd_metric_workspace_bytes(int ns, int n);
 int strotss_remd_metric_fwd_bwd(const float* style, int ns, const float* pred, int n, int d, int ld, int metric,
-                                float gscale, float* gpred, float* loss_out, void* workspace,
+                                float gscale, float* gpred, float* loss_out, int flags, void* workspace,
                                 size_t workspace_bytes, void* stream);
 size_t strotss_moment_workspace_bytes(int n, int ld);
 /* style side of moment_matching, once per scale: mean_out(ld), cov_out(ld,ld) = biased covariance */

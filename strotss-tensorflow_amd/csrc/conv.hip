@@ -271,8 +271,18 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const f32x4* __
                                                                  const f32x4* __restrict__ mask, int relu,
                                                                  f32x4* __restrict__ out, int accumulate) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
+    // the partial tiles are added in split order (bitwise reproducible), eight loads in flight at a time: a thread's chain
+    // of up to 72 dependent L2 round trips was the whole 9 us of this kernel on the 8 x 8 and 4 x 4 maps
     f32x4 v = part[e];
-    for (int sp = 1; sp < nsplit; ++sp) v = v + part[(size_t)sp * total4 + e];
+    int sp = 1;
+    for (; sp + 8 <= nsplit; sp += 8) {
+      f32x4 p8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p8[u] = part[(size_t)(sp + u) * total4 + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v = v + p8[u];
+    }
+    for (; sp < nsplit; ++sp) v = v + part[(size_t)sp * total4 + e];
     if (bias) v = v + bias[e % cout4];
     if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     if (mask) {

@@ -198,25 +198,39 @@ __global__ __launch_bounds__(DRAW_T) void index_draw_kernel(strotss_draw_t d) {
     }
   }
   __syncthreads();
-  if (tid >= n_out) list[tid] = ~0ull;
-  __syncthreads();
-  // ---- bitonic sort of the 1024 slots, ascending by (key, candidate)
+  // ---- bitonic sort of the 1024 slots, ascending by (key, candidate): one element per thread, kept in registers.  The 45
+  // stages whose partner lies within the wave exchange by lane shuffles (no barrier); the 10 cross-wave stages go through
+  // LDS, alternating between two buffers (`list` and the histogram's space, free by now) so that ONE barrier per stage is
+  // enough -- the kernel is a single workgroup of 16 waves and was spending most of its time at its ~85 barriers.
+  unsigned long long v = tid < n_out ? list[tid] : ~0ull;
+  unsigned long long* const xbuf[2] = {list, reinterpret_cast<unsigned long long*>(hist)};
+  int flip = 0;
+  __syncthreads();                                   // every thread holds its element before `list` is written again
+#pragma unroll
   for (int k = 2; k <= DRAW_T; k <<= 1) {
+#pragma unroll
     for (int j = k >> 1; j > 0; j >>= 1) {
-      const int p = tid ^ j;
-      if (p > tid) {
-        const unsigned long long a = list[tid], b = list[p];
-        const bool up = (tid & k) == 0;
-        if ((a > b) == up) { list[tid] = b; list[p] = a; }
+      unsigned long long pv;
+      if (j < 64) {
+        const unsigned lo = __shfl_xor((unsigned)v, j, 64), hi = __shfl_xor((unsigned)(v >> 32), j, 64);
+        pv = ((unsigned long long)hi << 32) | lo;
+      } else {
+        unsigned long long* buf = xbuf[flip];
+        buf[tid] = v;
+        __syncthreads();
+        pv = buf[tid ^ j];
+        flip ^= 1;
       }
-      __syncthreads();
+      const bool lower = (tid & j) == 0, up = (tid & k) == 0;
+      const unsigned long long lo64 = v < pv ? v : pv, hi64 = v < pv ? pv : v;
+      v = (lower == up) ? lo64 : hi64;
     }
   }
   float* out = d.idx[r];
   if (tid < d.sample_size) {
     float fx = 0.f, fy = 0.f;
     if (tid < n_out) {
-      const int c = (int)(unsigned)(list[tid] & 0xFFFFFFFFull);
+      const int c = (int)(unsigned)(v & 0xFFFFFFFFull);
       fx = (float)(off_x + (c % nx) * d.step_x);
       fy = (float)(off_y + (c / nx) * d.step_y);
     }

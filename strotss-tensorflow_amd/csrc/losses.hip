@@ -264,7 +264,7 @@ __global__ __launch_bounds__(1024) void col_min_final_select_kernel(const float*
                                                                     float* __restrict__ cmin, float* __restrict__ ccnt,
                                                                     const float* __restrict__ rowmin, int rows,
                                                                     int col_is_x, float* __restrict__ loss_out,
-                                                                    int* __restrict__ sel) {
+                                                                    int* __restrict__ sel, int swapped) {
   __shared__ float red[16];
   float a = 0.f, b = 0.f;
   for (int j = threadIdx.x; j < n; j += 1024) {
@@ -291,7 +291,9 @@ __global__ __launch_bounds__(1024) void col_min_final_select_kernel(const float*
   if (threadIdx.x == 0) {
     const float mc = a / (float)n, mr = b / (float)rows;
     const float rx = col_is_x ? mc : mr, ry = col_is_x ? mr : mc;
-    const int s = rx >= ry;
+    // tf.maximum(R_X, R_Y) sends a tie to its FIRST argument.  swapped: the caller asked for the gradient w.r.t. the
+    // reference's first argument and passed it as `pred` -- the kernel's "style" side is then the reference's R_Y
+    const int s = swapped ? (rx > ry) : (rx >= ry);
     loss_out[0] = s ? rx : ry;
     sel[0] = s;
   }
@@ -1030,6 +1032,13 @@ int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, co
   return st_selfsim_bwd_gemm(s.W, ldm, ldm, style, pred, s.rp, s.q, n, ld, gscale, gpred, st);
 }
 
+int strotss_rows_gemm_bwd(const float* W, int ldw, int k, const float* B, const float* x, const float* r, const float* q,
+                          int n, int ld, float g, float* dx, void* stream) {
+  ST_CHECK_ARG(W && B && x && r && q && dx && n > 0 && k > 0 && k <= ldw && ld > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(ldw % 32 == 0 && ld % 32 == 0, STROTSS_EALIGN);
+  return st_selfsim_bwd_gemm(W, ldw, ldw, B, x, r, q, n, ld, g, dx, (hipStream_t)stream);
+}
+
 size_t strotss_remd_workspace_bytes(int ns, int n, int ld) {
   Workspace w = Workspace::planner();
   RemdWs s;
@@ -1041,7 +1050,7 @@ size_t strotss_remd_workspace_bytes(int ns, int n, int ld) {
 // cost matrix on the f32 MFMA from the rows themselves)
 static int remd_cos_core(const float* style, const float* rs, const __bf16* xs, int ns, const float* pred, const float* rp,
                          const __bf16* xp, int n, int ld, float gscale, float* gpred, float* loss_out, RemdWs& s,
-                         hipStream_t st) {
+                         hipStream_t st, int swapped = 0) {
   // pred-major cost matrix Ct[j][i] (bitwise the transpose of cosine_distance(style, pred): same products, same k
   // order), so that the backward kernel's scans of "column j" are contiguous: minima over i per prediction row j
   // are row minima (cmin), minima over j per style row i column minima (rmin)
@@ -1051,14 +1060,14 @@ static int remd_cos_core(const float* style, const float* rs, const __bf16* xs, 
   hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.cmin,
                      s.ccnt, s.pmin, s.pcnt);
   hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin, s.rcnt,
-                     s.cmin, n, 1, loss_out, s.sel);
+                     s.cmin, n, 1, loss_out, s.sel, swapped);
   hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, ldt, style, rs, ns, pred, rp, n,
                      ld, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
   ST_LAUNCH_RET();
 }
 
 int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n, int d,
-                             int ld, float gscale, float* gpred, float* loss_out, void* workspace,
+                             int ld, float gscale, float* gpred, float* loss_out, int flags, void* workspace,
                              size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(style && rs && pred && gpred && loss_out && workspace && ns > 0 && feat_ok(n, d, ld),
                STROTSS_EINVAL);
@@ -1077,7 +1086,7 @@ int strotss_remd_cos_fwd_bwd(const float* style, const float* rs, int ns, const 
   }
   LAUNCH_OK();
   return remd_cos_core(style, rs, x3 ? s.xs : nullptr, ns, pred, s.rp, x3 ? s.xp : nullptr, n, ld, gscale, gpred, loss_out, s,
-                       st);
+                       st, flags & STROTSS_REMD_SWAPPED);
 }
 
 int strotss_selfsim_pred_panels(void* workspace, size_t workspace_bytes, int n, int ld, const float** inv_norm,
@@ -1113,8 +1122,8 @@ size_t strotss_remd_metric_workspace_bytes(int ns, int n) {
 }
 
 int strotss_remd_metric_fwd_bwd(const float* style, int ns, const float* pred, int n, int d, int ld, int metric,
-                                float gscale, float* gpred, float* loss_out, void* workspace, size_t workspace_bytes,
-                                void* stream) {
+                                float gscale, float* gpred, float* loss_out, int flags, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(style && pred && gpred && loss_out && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
   ST_CHECK_ARG(metric == STROTSS_METRIC_L2 || metric == STROTSS_METRIC_BOTH, STROTSS_EINVAL);
   ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
@@ -1135,14 +1144,14 @@ int strotss_remd_metric_fwd_bwd(const float* style, int ns, const float* pred, i
   hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, s.C, n, ns, ldt, s.cmin,
                      s.ccnt, s.pmin, s.pcnt);
   hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, s.pmin, s.pcnt, ns, ldt, s.rmin, s.rcnt,
-                     s.cmin, n, 1, loss_out, s.sel);
+                     s.cmin, n, 1, loss_out, s.sel, flags & STROTSS_REMD_SWAPPED);
   hipLaunchKernelGGL(remd_generic_bwd_kernel, dim3(n), dim3(256), 0, st, s.C, s.S, ldt, style, s.rs, ns, pred, s.rp, n, ld,
                      (float)d, metric, s.rmin, s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred);
   ST_LAUNCH_RET();
 }
 
 int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, int n, int ld, int rgb_to_yuv,
-                                 float gscale, float* gpred, float* loss_out, void* workspace,
+                                 float gscale, float* gpred, float* loss_out, int flags, void* workspace,
                                  size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(style && pred && gpred && loss_out && workspace && ns > 0 && n > 0 && ld >= 3, STROTSS_EINVAL);
   Workspace w(workspace, workspace_bytes);
@@ -1155,7 +1164,7 @@ int strotss_palette_remd_fwd_bwd(const float* style, int ns, const float* pred, 
   hipLaunchKernelGGL(palette_minima_kernel, dim3(ns + n), dim3(256), 0, st, s.ys, ns, s.yp, n, s.rmin, s.rcnt, s.cmin,
                      s.ccnt);
   hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, (const float*)nullptr, (const float*)nullptr,
-                     n, 0, s.cmin, s.ccnt, s.rmin, ns, 0, loss_out, s.sel);
+                     n, 0, s.cmin, s.ccnt, s.rmin, ns, 0, loss_out, s.sel, flags & STROTSS_REMD_SWAPPED);
   hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, s.ys, ns, s.yp, n, s.rmin,
                      s.rcnt, s.cmin, s.ccnt, s.sel, gscale, gpred, ld, rgb_to_yuv);
   ST_LAUNCH_RET();

@@ -98,17 +98,18 @@ SIGNATURES = {
     "strotss_l2_distance": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
     "strotss_row_inv_norm_x3": (_I, [_P, _I, _I, _P, _P, _P]),
     "strotss_cosine_distance_x3": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _I, _P]),
+    "strotss_rows_gemm_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _P, _P]),
     "strotss_selfsim_workspace_bytes": (_Z, [_I, _I]),
     "strotss_selfsim_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "strotss_sinkhorn_workspace_bytes": (_Z, [_I, _I, _I]),
     "strotss_sinkhorn_cos_fwd_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P, _Z, _P]),
     "strotss_remd_workspace_bytes": (_Z, [_I, _I, _I]),
-    "strotss_remd_cos_fwd_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_remd_cos_fwd_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P, _Z, _P]),
     "strotss_selfsim_pred_panels": (_I, [_P, _Z, _I, _I, C.POINTER(_P), C.POINTER(_P)]),
     "strotss_remd_cos_fwd_bwd_panels": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
-    "strotss_palette_remd_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_palette_remd_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P, _Z, _P]),
     "strotss_remd_metric_workspace_bytes": (_Z, [_I, _I]),
-    "strotss_remd_metric_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_remd_metric_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _Z, _P]),
     "strotss_moment_workspace_bytes": (_Z, [_I, _I]),
     "strotss_moment_stats": (_I, [_P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "strotss_moment_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),

@@ -508,12 +508,13 @@ _selfsim_record = None
 remd_borrow_stats = {"borrowed": 0, "plain": 0}      # which path remd_cos_fwd_bwd_after_selfsim took (tests read it)
 
 
-def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out):
+def remd_cos_fwd_bwd(style, rs, ns, pred, n, d, gscale, gpred, loss_out, swapped=False):
+    """swapped: `pred` is the reference's FIRST argument (gradient to the target side; STROTSS_REMD_SWAPPED)"""
     l = _hip.lib()
     nb = l.strotss_remd_workspace_bytes(ns, n, pred.shape[1])
     ws = workspaces.get("remd", nb, pred.device)
     check(l.strotss_remd_cos_fwd_bwd(ptr(style), ptr(rs), ns, ptr(pred), n, d, pred.shape[1], gscale,
-                                     ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "remd_cos_fwd_bwd")
+                                     ptr(gpred), ptr(loss_out), int(swapped), ptr(ws), nb, stream_ptr()), "remd_cos_fwd_bwd")
 
 
 def remd_cos_fwd_bwd_after_selfsim(style, rs, style_panels, ns, pred, n, d, gscale, gpred, loss_out):
@@ -552,26 +553,36 @@ def sinkhorn_cos_fwd_bwd(style, rs, ns, pred, n, d, l, n_iter, gscale, gpred, lo
           "sinkhorn_cos_fwd_bwd")
 
 
-def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out, rgb_to_yuv=True):
+def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out, rgb_to_yuv=True, swapped=False):
     l = _hip.lib()
     nb = l.strotss_remd_workspace_bytes(ns, n, 0)
     ws = workspaces.get("remd", nb, pred.device)
     assert style.shape[1] == pred.shape[1]
     check(l.strotss_palette_remd_fwd_bwd(ptr(style), ns, ptr(pred), n, pred.shape[1], int(rgb_to_yuv), gscale,
-                                         ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "palette_remd_fwd_bwd")
+                                         ptr(gpred), ptr(loss_out), int(swapped), ptr(ws), nb, stream_ptr()), "palette_remd_fwd_bwd")
 
 
 REMD_METRICS = {"l2": 1, "both": 2}      # STROTSS_METRIC_L2 / STROTSS_METRIC_BOTH (include/strotss_hip.h)
 
 
-def remd_metric_fwd_bwd(style, ns, pred, n, d, metric: str, gscale, gpred, loss_out):
+def remd_metric_fwd_bwd(style, ns, pred, n, d, metric: str, gscale, gpred, loss_out, swapped=False):
     """relaxed_emd with dist_metrics 'l2' / 'both' at any width (reference losses.py:18-28, 69-80)."""
     l = _hip.lib()
     nb = l.strotss_remd_metric_workspace_bytes(ns, n)
     ws = workspaces.get("remd_metric", nb, pred.device)
     assert style.shape[1] == pred.shape[1]
     check(l.strotss_remd_metric_fwd_bwd(ptr(style), ns, ptr(pred), n, d, pred.shape[1], REMD_METRICS[metric], gscale,
-                                        ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()), "remd_metric_fwd_bwd")
+                                        ptr(gpred), ptr(loss_out), int(swapped), ptr(ws), nb, stream_ptr()), "remd_metric_fwd_bwd")
+
+
+def rows_gemm_bwd(W, k, B, x, r, q, n, g, dx):
+    """dx[i, :] += g * r[i] * (sum_j W[i, j] B[j, :] - x[i, :] * r[i] * q[i])   for i < n, j < k  (strotss_rows_gemm_bwd):
+    the backward of a pairwise distance matrix w.r.t. one of its two row sets (reference losses.py:12-24 under
+    tape.gradient) -- W = d(loss)/d(product) scaled by the other side's factors, q = the normalisation's rank-one term."""
+    assert W.is_contiguous() and B.is_contiguous() and x.is_contiguous() and dx.is_contiguous()
+    assert int(W.shape[1]) % 32 == 0 and int(B.shape[1]) == int(x.shape[1]) == int(dx.shape[1]) and int(B.shape[0]) >= int(W.shape[1])
+    check(_hip.lib().strotss_rows_gemm_bwd(ptr(W), int(W.shape[1]), int(k), ptr(B), ptr(x), ptr(r), ptr(q), n, int(x.shape[1]),
+                                           float(g), ptr(dx), stream_ptr()), "rows_gemm_bwd")
 
 
 def moment_stats(x, n, d):

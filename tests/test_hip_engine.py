@@ -297,9 +297,74 @@ def test_losses_api_autograd():
     assert (L.l2_distance(xd[:, :3], yd.detach()[:, :3]).cpu().double()
             - O.l2_distance(xt[:, :3], yt.detach()[:, :3])).abs().max() < 1e-5
     with pytest.raises(NotImplementedError):
-        L.self_similarity(yd, cd.clone().requires_grad_(True))
-    with pytest.raises(NotImplementedError):
         L.sinkhorn_knopp(xd, yd, distance='l2')
+
+
+@pytest.mark.parametrize("shape", [(96, 80, 131), (64, 100, 3), (70, 70, 35)])
+def test_losses_differentiate_both_arguments_like_tf(shape):
+    """TF's tape differentiates BOTH arguments of every loss and distance (reference losses.py:12-24, 39-80); run_strotss.py
+    only ever asks for the prediction side.  The operator surface gives both: value and the two gradients of
+    moment_matching, self_similarity (equal row counts), relaxed_emd under every metric, and of the matrices cosine_distance /
+    l2_distance under a random upstream gradient, against the float64 autograd restatement."""
+    from nn import losses as L
+    n, ns, d = shape
+    rng = np.random.default_rng(n + 3 * ns + d)
+    mk = lambda r, c: np.abs(rng.standard_normal((r, c))) + 0.01
+    x, y = mk(ns, d), mk(n, d)
+
+    def both(fn_ref, fn_hip, a, b, tol, upstream=None):
+        at, bt = torch.from_numpy(a).clone().requires_grad_(True), torch.from_numpy(b).clone().requires_grad_(True)
+        ref = fn_ref(at, bt)
+        ad = torch.from_numpy(a).float().to(DEV).requires_grad_(True)
+        bd = torch.from_numpy(b).float().to(DEV).requires_grad_(True)
+        got = fn_hip(ad, bd)
+        if upstream is None:
+            ga, gb = torch.autograd.grad(ref, (at, bt))
+            got.backward()
+            assert abs(float(got) - float(ref)) < 5e-5 * max(1.0, abs(float(ref))), (float(got), float(ref))
+        else:
+            ga, gb = torch.autograd.grad((ref * upstream).sum(), (at, bt))
+            (got * upstream.float().to(DEV)).sum().backward()
+            assert float((got.detach().cpu().double() - ref.detach()).abs().max()) < 1e-5
+        for name, g, want in (("first", ad.grad, ga), ("second", bd.grad, gb)):
+            rel = float((g.cpu().double() - want).norm() / max(1e-30, float(want.norm())))
+            assert rel < tol, (name, rel)
+        # one side alone gives the same gradient as asking for both
+        ad2 = torch.from_numpy(a).float().to(DEV).requires_grad_(True)
+        got2 = fn_hip(ad2, torch.from_numpy(b).float().to(DEV))
+        (got2 if upstream is None else (got2 * upstream.float().to(DEV)).sum()).backward()
+        assert torch.equal(ad2.grad, ad.grad)
+
+    both(O.moment_matching, L.moment_matching, x, y, 5e-3)
+    for metric in ("cosine", "l2", "both"):
+        both(lambda a, b: O.relaxed_emd(a, b, metric), lambda a, b: L.relaxed_emd(a, b, metric), x, y, 5e-3)
+    if n == ns:
+        both(O.self_similarity, L.self_similarity, x, y, 5e-3)
+    G = torch.from_numpy(rng.standard_normal((ns, n)))
+    both(O.cosine_distance, L.cosine_distance, x, y, 2e-4, upstream=G)
+    both(O.l2_distance, L.l2_distance, x, y, 2e-4, upstream=G)
+    # dist_metrics['both'] composes the two differentiable matrices
+    both(lambda a, b: O.cosine_distance(a, b) + O.l2_distance(a, b), L.dist_metrics['both'], x, y, 2e-4, upstream=G)
+
+
+def test_relaxed_emd_target_side_gradient_keeps_tf_maximum_tie_rule():
+    """x == y: R_X == R_Y bitwise and the two branches differ; tf.maximum sends the tie to its FIRST argument R_X (rows of
+    x, minima over y).  The gradient w.r.t. x comes from the kernels with the roles exchanged (STROTSS_REMD_SWAPPED): it must
+    still be the R_X branch's, i.e. equal the float64 restatement's, for every metric."""
+    from nn import losses as L
+    rng = np.random.default_rng(3)
+    x = np.abs(rng.standard_normal((48, 19))) + 0.01
+    x[5] = x[2]                                    # a duplicated row: the two branches' tie-splitting differs
+    for metric in ("cosine", "l2", "both"):
+        at, bt = torch.from_numpy(x).clone().requires_grad_(True), torch.from_numpy(x).clone().requires_grad_(True)
+        ref = O.relaxed_emd(at, bt, metric)
+        ga, gb = torch.autograd.grad(ref, (at, bt))
+        ad = torch.from_numpy(x).float().to(DEV).requires_grad_(True)
+        bd = torch.from_numpy(x).float().to(DEV).requires_grad_(True)
+        L.relaxed_emd(ad, bd, metric).backward()
+        for name, g, want in (("first", ad.grad, ga), ("second", bd.grad, gb)):
+            err = float((g.cpu().double() - want).abs().max())
+            assert err < 2e-3 * max(1e-6, float(want.abs().max())) + 1e-7, (metric, name, err, float(want.abs().max()))
 
 
 @pytest.mark.parametrize("distance", ["l2", "both", "cosine"])

@@ -491,6 +491,7 @@ struct EpiMomentFwdX3 {
   static constexpr bool SYMM = true;
   static constexpr int symm = 1;
   const float* Sx; __bf16* Tp; int ld; int M, N; float inv_n; float* partial;
+  unsigned first_block = 0;      // this problem's first workgroup in a grouped launch (partial[] is indexed per problem)
   __device__ __forceinline__ void set_batch(int) {}
   // The style covariance entries of the tile are fetched before the main loop (clamped addresses, no conditions): one
   // workgroup per CU has nothing to hide a load behind (inside `if`s in the epilogue they cost 45 us per tile).
@@ -506,7 +507,7 @@ struct EpiMomentFwdX3 {
   }
   __device__ __forceinline__ void finish(float* red, float local) const {
     const float s = block_sum_256(local, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    if (threadIdx.x == 0) partial[blockIdx.x - first_block] = s;
   }
 };
 // Writes the tile's sign values into the single-plane panel Tp -- as they stand AND transposed (tiles below the
@@ -581,7 +582,7 @@ struct EpiSymScaleX3 : X3NoPrefetch<EpiSymScaleX3> {
   __device__ __forceinline__ void finish(float*, float) const {}
 };
 int st_gram_tn_x3(const void* Pt, int npad, int ld, float alpha, float* C, hipStream_t s) {
-  using Cfg = X3Cfg<128>;
+  using Cfg = X3CfgK16<3>;      // (round 4: the K16 ring, as st_moment_fwd_x3 and the grouped forward launch)
   EpiSymScaleX3 e{{}, C, ld, ld, ld, alpha};
   const int g = cdiv(ld, 128);
   hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiSymScaleX3, X3Mirror<Cfg>>), dim3(g * (g + 1) / 2), dim3(Cfg::NT), 0, s,
@@ -591,12 +592,53 @@ int st_gram_tn_x3(const void* Pt, int npad, int ld, float alpha, float* C, hipSt
 
 int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
                      int* n_partial, hipStream_t s) {
-  using Cfg = X3Cfg<128>;
-  EpiMomentFwdX3 e{Sx, (__bf16*)Tp, ld, ld, ld, inv_n, partial};
+  using Cfg = X3CfgK16<3>;      // 72 KB ring, two workgroups per CU: the configuration the grouped forward launch runs it in
+  EpiMomentFwdX3 e{Sx, (__bf16*)Tp, ld, ld, ld, inv_n, partial, 0u};
   const int g = cdiv(ld, 128);
   *n_partial = g * (g + 1) / 2;                      // upper-triangular launch: 171 workgroups at ld = 2208, one round
   hipLaunchKernelGGL((gemm_x3_kernel<Cfg, EpiMomentFwdX3, X3MomentStore<Cfg>>), dim3(g * (g + 1) / 2), dim3(Cfg::NT), 0, s,
                      (const __bf16*)Pt, ld, 0LL, (const __bf16*)Pt, ld, 0LL, npad, e, X3MomentStore<Cfg>{});
+  ST_LAUNCH_RET();
+}
+
+// The three forward products of a train step's loss section in ONE launch (gemm_x3_group3_kernel): the covariance of the
+// centred prediction rows against the style covariance (st_moment_fwd_x3: upper-triangular 128 x 128 tiles, here on the
+// K16 ring so that two workgroups share a CU with the 64 x 64 tiles), the two symmetric self-similarity cost matrices
+// (st_cosine_distance_x3, batch 2) and the prediction x style cost matrix of the relaxed EMD (pred-major).  Each problem
+// runs the tile code of its stand-alone launch: bitwise the same matrices.
+int st_loss_forward_group_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
+                             int* n_partial,
+                             const void* xp, const float* rp, int n, long long pstride, long long rstride, float* Dx,
+                             int ldc, long long dstride,
+                             const void* xs, const float* rs, int ns, float* Ct, int ldt, hipStream_t s) {
+  using CM = X3CfgK16<3>;
+  using CC = X3Cfg<64>;
+  const unsigned gm = cdiv(ld, 128), nm = gm * (gm + 1) / 2;
+  const unsigned g = cdiv(n, 64), nc = g * (g + 1) / 2 * 2;
+  const unsigned gs = cdiv(ns, 64), nr = g * gs;
+  *n_partial = (int)nm;
+  X3Problem<EpiMomentFwdX3> p0{(const __bf16*)Pt, ld, 0LL, (const __bf16*)Pt, ld, 0LL, npad,
+                               EpiMomentFwdX3{Sx, (__bf16*)Tp, ld, ld, ld, inv_n, partial, 0u}, 0, 0, nm};
+  X3Problem<EpiCosDistX3> p1{(const __bf16*)xp, n, pstride, (const __bf16*)xp, n, pstride, ld,
+                             EpiCosDistX3{{rp, rp, Dx, ldc, n, n, 1}, {}, rstride, dstride}, 0, 0, nc};
+  // prediction-major cost matrix Ct[j][i] = 1 - <yhat_j, xhat_i> (remd_cos_core): full grid, 2-D XCD blocking as stand-alone
+  int bh = 0, bw = 0;
+  if ((gs * g) % 8 == 0) {
+    const unsigned per = gs * g / 8;
+    unsigned best = 0;
+    for (unsigned h = 1; h <= per; ++h) {
+      if (per % h || g % h) continue;
+      const unsigned w = per / h;
+      if (gs % w) continue;
+      if (!best || h + w < best + per / best) best = h;
+    }
+    if (best) { bh = (int)best; bw = (int)(per / best); }
+  }
+  X3Problem<EpiCosDistX3> p2{(const __bf16*)xp, n, 0LL, (const __bf16*)xs, ns, 0LL, ld,
+                             EpiCosDistX3{{rp, rs, Ct, ldt, n, ns, 0}, {}, 0LL, 0LL}, bh, bw, nr};
+  const unsigned grid = x3_pad8(nm) + x3_pad8(nc) + nr;
+  hipLaunchKernelGGL((gemm_x3_group3_kernel<CM, EpiMomentFwdX3, X3MomentStore<CM>, CC, EpiCosDistX3, X3Mirror<CC>, CC, EpiCosDistX3,
+                                            X3Mirror<CC>>), dim3(grid), dim3(256), 0, s, p0, p1, p2);
   ST_LAUNCH_RET();
 }
 

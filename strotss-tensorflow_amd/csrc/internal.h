@@ -39,6 +39,10 @@ int st_selfsim_bwd_x3(const void* Mp, int kpad, const void* Xt, const float* x, 
 int st_gram_tn_x3(const void* Pt, int npad, int ld, float alpha, float* C, hipStream_t s);
 int st_moment_fwd_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
                      int* n_partial, hipStream_t s);
+int st_loss_forward_group_x3(const void* Pt, int npad, int ld, const float* Sx, void* Tp, float inv_n, float* partial,
+                             int* n_partial, const void* xp, const float* rp, int n, long long pstride, long long rstride,
+                             float* Dx, int ldc, long long dstride, const void* xs, const float* rs, int ns, float* Ct,
+                             int ldt, hipStream_t s);
 int st_moment_bwd_x3(const void* Pc, int n, int ld, const void* Tp, float alpha, const float* bias, float bias_scale,
                      float* dY, hipStream_t s);
 int st_gemm_x3_batched(const void* A, const void* B, float* C, int ldc, long long strideC, int M, int N, int K,

@@ -1235,4 +1235,71 @@ int strotss_moment_fwd_bwd(const float* style_mean, const float* style_cov, cons
   return st_moment_bwd_gemm(s.cy, n, ld, s.T, a, s.sgn, b, gpred, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The three feature-space losses of one train step (run_strotss.py:131-142: self_similarity + moment_matching + relaxed_emd
+// on the same prediction rows) in ONE call whose three forward GEMMs share ONE launch (st_loss_forward_group_x3).  Every
+// kernel, tile shape and summation order is that of the three separate entry points called in this order
+// (strotss_selfsim_fwd_bwd, strotss_moment_fwd_bwd, strotss_remd_cos_fwd_bwd_panels): bit for bit the same losses and
+// gradient rows; two launches and the idle slots of three underfilled GEMMs less.  bf16x3 core only (STROTSS_X3 / _COST /
+// _MOMENT = 0: STROTSS_EINVAL, the caller takes the separate entry points).
+size_t strotss_step_losses_workspace_bytes(int ns, int n, int ld) {
+  Workspace w = Workspace::planner();
+  SelfsimWs a; MomentWs b; RemdWs c;
+  a.plan(w, n, ld); b.plan(w, n, ld); c.plan(w, ns, n, ld);
+  return w.off;
+}
+
+int strotss_step_losses_fwd_bwd(const float* pred, const float* content, int n, int d, int ld, const float* style,
+                                const float* style_inv_norm, const void* style_panels, int ns, const float* style_mean,
+                                const float* style_cov, float g_content, float g_moment, float g_remd, float* gpred,
+                                float* loss_content, float* loss_moment, float* loss_remd, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(pred && content && style && style_inv_norm && style_panels && style_mean && style_cov && gpred && loss_content &&
+               loss_moment && loss_remd && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(ns <= REMD_MAX_LIST, STROTSS_ERANGE);
+  ST_CHECK_ARG(cost_x3() && moment_x3(), STROTSS_EINVAL);
+  Workspace w(workspace, workspace_bytes);
+  SelfsimWs s; MomentWs m; RemdWs r;
+  ST_CHECK_ARG(s.plan(w, n, ld) && m.plan(w, n, ld) && r.plan(w, ns, n, ld), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  const int ldc = s.ldc;
+  // ---- prologues: reciprocal norms + x3 panels of the prediction and content rows; column means, centred panels
+  hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4), 2), dim3(256), 0, st, pred, n, ld, s.rp, s.xp, content, n, s.rc,
+                     s.xc);
+  hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(ld, 64), COL_CHUNKS), dim3(256), 0, st, pred, n, ld, m.psum);
+  hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, m.rows / 32), dim3(256), 0, st, pred, n, m.rows, ld,
+                     (const float*)nullptr, m.Pc, m.Pt, (const float*)m.psum, m.mean);
+  LAUNCH_OK();
+  // ---- the three forward products, one launch
+  int n_partial = 0;
+  CHK(st_loss_forward_group_x3(m.Pt, m.rows, ld, style_cov, m.Tp, 1.0f / (float)n, m.partial, &n_partial,
+                               s.xp, s.rp, n, s.xc - s.xp, s.rc - s.rp, s.Dx, ldc, s.Dy - s.Dx,
+                               style_panels, style_inv_norm, ns, r.C, r.ldt, st));
+  // ---- self-similarity: statistics, symmetrised gradient matrix, backward GEMM
+  hipLaunchKernelGGL(selfsim_rowstat_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, n, ldc, 1.0f / (float)n, s.sx, s.sy,
+                     s.tt, s.lossrow);
+  hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, s.tt, s.rp, n, ldc, ldc,
+                     1.0f / (float)n, s.Mq, s.qdot, s.mp, s.lossrow, 1.0f / (float)n, loss_content);
+  hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, ldc / 32), dim3(256), 0, st, pred, n, ldc, ld, (const float*)nullptr,
+                     (__bf16*)nullptr, s.xt);
+  LAUNCH_OK();
+  CHK(st_selfsim_bwd_x3(s.mp, ldc, s.xt, pred, s.rp, s.qdot, n, ld, g_content, gpred, st));
+  // ---- moment matching: loss scalars + mean-gradient signs, backward GEMM
+  hipLaunchKernelGGL(moment_finalize_kernel, dim3(1), dim3(256), 0, st, m.partial, n_partial, style_mean, m.mean, d, ld,
+                     m.sgn, loss_moment);
+  LAUNCH_OK();
+  CHK(st_moment_bwd_x3(m.Pc, n, ld, m.Tp, g_moment * 2.0f / ((float)n * (float)d * (float)d), m.sgn,
+                       g_moment / ((float)d * (float)n), gpred, st));
+  // ---- relaxed EMD on the cost matrix the grouped launch left in r.C: minima, branch, sparse backward
+  const int ldt = r.ldt;
+  hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, r.C, n, ns, ldt, r.cmin,
+                     r.ccnt, r.pmin, r.pcnt);
+  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, r.pmin, r.pcnt, ns, ldt, r.rmin, r.rcnt,
+                     r.cmin, n, 1, loss_remd, r.sel, 0);
+  hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, r.C, ldt, style, style_inv_norm, ns, pred, s.rp, n,
+                     ld, r.rmin, r.rcnt, r.cmin, r.ccnt, r.sel, g_remd, gpred);
+  ST_LAUNCH_RET();
+}
+
 }  // extern "C"

@@ -399,13 +399,15 @@ struct X3NoPrefetch {
 // Epilogues as in gemm.hip (apply / finish; SYMM epilogues also value / mirror and a run-time `symm` switch: then
 // the LAUNCH holds only the tiles on or above the diagonal, gx (gx + 1) / 2 workgroups, and every tile below is
 // written as the transpose of the one above, bitwise symmetric).
+// One workgroup's tile of such a product: `bid` of `nblk` workgroups (the launch's own, or one problem's share of a grouped
+// launch: gemm_x3_group3_kernel below).  `lds` holds >= Cfg::LDS_BYTES, 1024-byte aligned.
 template <class Cfg, class Epi, class Mirror>
-__global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restrict__ A, int M, long long strideA,
-                                                          const __bf16* __restrict__ B, int N, long long strideB,
-                                                          int K, Epi epi, Mirror mirror, int xbh = 0, int xbw = 0) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDS_BYTES];
+__device__ __forceinline__ void gemm_x3_tile(unsigned char* lds, unsigned bid, unsigned nblk, const __bf16* __restrict__ A, int M,
+                                             long long strideA, const __bf16* __restrict__ B, int N, long long strideB, int K,
+                                             const Epi& epi_in, const Mirror& mirror, int xbh, int xbw) {
+  Epi epi = epi_in;                                 // (set_batch moves its pointers)
   const unsigned gx = (N + Cfg::BN - 1) / Cfg::BN, gy = (M + Cfg::BM - 1) / Cfg::BM;
-  unsigned tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  unsigned tile = xcd_swizzle(bid, nblk);
   unsigned bz = 0;
   int m0, n0;
   bool tri = false;
@@ -472,6 +474,48 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restri
   }
   __syncthreads();
   epi.finish(reinterpret_cast<float*>(lds), local);
+}
+
+template <class Cfg, class Epi, class Mirror>
+__global__ __launch_bounds__(Cfg::NT) void gemm_x3_kernel(const __bf16* __restrict__ A, int M, long long strideA,
+                                                          const __bf16* __restrict__ B, int N, long long strideB,
+                                                          int K, Epi epi, Mirror mirror, int xbh = 0, int xbw = 0) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDS_BYTES];
+  gemm_x3_tile<Cfg, Epi, Mirror>(lds, blockIdx.x, gridDim.x, A, M, strideA, B, N, strideB, K, epi, mirror, xbh, xbw);
+}
+
+// THREE independent products in ONE launch (round 4): the forward cost / covariance matrices of a train step's loss section
+// (run_strotss.py:33-40, nn/losses.py:39-80 of the reference) are mutually independent, each underfills the chip on its
+// own (272, 256 and 171 workgroups for 512 two-per-CU slots) and a dependent launch costs ~5 us end to end.  Problem p owns
+// the workgroups [first_p, first_p + n_p) of the grid, first_p a multiple of 8 so that a problem's local workgroup ids keep
+// the launch's XCD round-robin (xcd_swizzle); the padding workgroups exit.  Every problem keeps its own tile
+// configuration, epilogue and product order: results are bit for bit those of three separate launches.
+template <class Epi>
+struct X3Problem {
+  const __bf16* A; int M; long long strideA;
+  const __bf16* B; int N; long long strideB;
+  int K; Epi epi; int xbh, xbw;
+  unsigned n;                                       // workgroups of this problem
+};
+__host__ __device__ __forceinline__ unsigned x3_pad8(unsigned n) { return (n + 7u) & ~7u; }
+template <class C0, class E0, class M0, class C1, class E1, class M1, class C2, class E2, class M2>
+__global__ __launch_bounds__(256) void gemm_x3_group3_kernel(X3Problem<E0> p0, X3Problem<E1> p1, X3Problem<E2> p2) {
+  static_assert(C0::NT == 256 && C1::NT == 256 && C2::NT == 256, "grouped x3 launch: 256-thread workgroups");
+  constexpr int L01 = C0::LDS_BYTES > C1::LDS_BYTES ? C0::LDS_BYTES : C1::LDS_BYTES;
+  constexpr int LDSB = L01 > C2::LDS_BYTES ? L01 : C2::LDS_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDSB];
+  unsigned b = blockIdx.x;
+  if (b < x3_pad8(p0.n)) {
+    if (b < p0.n) { M0 m; gemm_x3_tile<C0, E0, M0>(lds, b, p0.n, p0.A, p0.M, p0.strideA, p0.B, p0.N, p0.strideB, p0.K, p0.epi, m, p0.xbh, p0.xbw); }
+    return;
+  }
+  b -= x3_pad8(p0.n);
+  if (b < x3_pad8(p1.n)) {
+    if (b < p1.n) { M1 m; gemm_x3_tile<C1, E1, M1>(lds, b, p1.n, p1.A, p1.M, p1.strideA, p1.B, p1.N, p1.strideB, p1.K, p1.epi, m, p1.xbh, p1.xbw); }
+    return;
+  }
+  b -= x3_pad8(p1.n);
+  if (b < p2.n) { M2 m; gemm_x3_tile<C2, E2, M2>(lds, b, p2.n, p2.A, p2.M, p2.strideA, p2.B, p2.N, p2.strideB, p2.K, p2.epi, m, p2.xbh, p2.xbw); }
 }
 
 // Row-major f32 (rows x ld, K <= ld columns used, K % 32 == 0) -> x3 panels, batched over blockIdx.y.

@@ -364,7 +364,9 @@ def test_relaxed_emd_target_side_gradient_keeps_tf_maximum_tie_rule():
         L.relaxed_emd(ad, bd, metric).backward()
         for name, g, want in (("first", ad.grad, ga), ("second", bd.grad, gb)):
             err = float((g.cpu().double() - want).abs().max())
-            assert err < 2e-3 * max(1e-6, float(want.abs().max())) + 1e-7, (metric, name, err, float(want.abs().max()))
+            # ('l2' at x == y: every minimum sits on the clamped diagonal, the reference's gradient is exactly zero; in f32
+            # |x|^2 + |y|^2 - 2 x.y of a row with itself is rounding noise around the 1e-6 clamp, worth ~1e-7 of gradient)
+            assert err < 2e-3 * float(want.abs().max()) + 2e-6, (metric, name, err, float(want.abs().max()))
 
 
 @pytest.mark.parametrize("distance", ["l2", "both", "cosine"])

@@ -195,7 +195,7 @@ def box_calibration(dev):
     return out
 
 
-FAMILIES = ["conv3x3_relu_fwd", "conv3x3_dgrad", "conv3x3_winograd_fwd", "conv3x3_winograd_dgrad", "selfsim_fwd_bwd",
+FAMILIES = ["conv3x3_relu_fwd", "conv3x3_dgrad", "conv3x3_winograd_fwd", "conv3x3_winograd_dgrad", "step_losses_fwd_bwd", "index_draw", "selfsim_fwd_bwd",
             "remd_cos_fwd_bwd", "moment_fwd_bwd", "palette_remd_fwd_bwd", "hypercol_scatter", "maxpool2_bwd", "maxpool2_fwd",
             "conv3x3_c3_fwd", "conv3x3_c3_dgrad", "rmsprop_step", "resize_bilinear", "fold_pyramid", "resize_bilinear_adjoint",
             "loss_section"]
@@ -402,8 +402,19 @@ def pairwise_roofline(dev, iters=50):
     # the bound of the instruction the kernel issues: the bf16x3 core spends 6 bf16 MFMA products per f32 product, so its
     # f32-equivalent ceiling is the dense bf16 peak / 6; with STROTSS_X3=0 the kernel runs on the f32 MFMA itself
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else F32_MFMA_PEAK_TFLOPS
+    # what actually bounds it (measured in rounds 2-4): the bytes a CU can take in.  A 64 x 64 tile stages
+    # (64 + 64 rows) x 64 B x 3 planes = 24 KiB per K-step of 32 through LDS-DMA; 256 tiles x 69 K-steps = 424 MB per launch, every
+    # byte entering some CU's LDS.  The guide's measured ceiling for L2-resident rows gathered into LDS is 66-73 GB/s per CU
+    # (MI355X_MICROARCH.md, "Indexed rows: gather into LDS"): 256 CUs x 70 GB/s = 17.9 TB/s.
+    ingest = None
+    if x3:
+        tiles, ksteps = (SAMPLES // 64) ** 2, ld // 32
+        gb = tiles * ksteps * (64 + 64) * 64 * 3 / 1e9
+        ingest = {"bytes_into_lds_per_launch_MB": round(gb * 1e3, 1), "achieved_TBps": round(gb / (ms * 1e-3) / 1e3, 2),
+                  "peak_TBps": 17.9, "frac": round(gb / (ms * 1e-3) / 1e3 / 17.9, 3),
+                  "peak_is": "256 CUs x 70 GB/s: the guide's measured LDS-DMA ingest of L2-resident rows per CU"}
     return {"kernel": kern, "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(tf / peak, 4), "avg_launch_us": round(ms * 1e3, 2), "traffic": None,
+            "frac": round(tf / peak, 4), "avg_launch_us": round(ms * 1e3, 2), "traffic": None, "cu_ingest": ingest,
             "peak_is": "dense bf16 MFMA 2500 TFLOP/s / 6 partial products (f32-equivalent)" if x3 else "dense f32 MFMA",
             "executed_bf16_tflops": round(6 * tf, 1) if x3 else None, "bf16_mfma_peak_tflops": BF16_MFMA_PEAK_TFLOPS if x3 else None,
             "vs_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)}
@@ -757,6 +768,7 @@ def main():
                          "pixel gradient per step; masked-strips: that masked pair sharded by image strips instead -- the sharding "
                          "that cuts trunk work (all strong scaling: value = steps/s of that one job)")
     ap.add_argument("--regions", type=int, default=4, help="--mode regions: number of mask regions (vertical bands)")
+    ap.add_argument("--no-long-window", action="store_true", help="skip the extra >= 200-replay window and the box calibration (profiling passes)")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (traffic from the committed profile)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rehearse", action="store_true", help="N-rank harness only (gloo, sleeping stand-in step, no GPU)")
@@ -835,7 +847,7 @@ def main():
     losses = eng.losses()
     # a window long enough to compare across runs whatever --steps was (the driver asks for 20 = 0.09 s): >= 200 replays
     long_window = None
-    if world == 1:
+    if world == 1 and not args.no_long_window:
         n_long = max(200, args.steps)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -843,7 +855,7 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t1
         long_window = {"steps": n_long, "ms_per_step": round(1e3 * el / n_long, 4), "steps_per_sec": round(n_long / el, 2)}
-    calib = box_calibration(dev) if rank == 0 else None
+    calib = box_calibration(dev) if (rank == 0 and not args.no_long_window) else None
 
     out = None
     if rank == 0:

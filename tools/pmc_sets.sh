@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter sets of the step's kernels on the GPU box: tools/pmc_sets.sh rNN  (writes gpurun_out/pmc_rNN/summary.txt -> copy to profiles/)
-# two separate --pmc passes of `bench.py --no-families --no-graph --steps 6` (counters serialise the kernels)
+# two separate --pmc passes of `bench.py --no-families --no-graph --no-long-window --steps 6 --warmup 2` (counters serialise the kernels)
 r=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$r
 mkdir -p $out && cd /tmp && export TMPDIR=/tmp

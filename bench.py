@@ -179,6 +179,22 @@ def box_calibration(dev):
             if best is None or tf > best[0]:
                 best = (tf, ghz, ms)
         out[name] = {"tflops": round(best[0], 1), "clock_ghz": round(best[1], 3), "ms": round(best[2], 2)}
+    # the loaded loop (random operands re-read from LDS, two waves per SIMD): the one that tells boxes apart
+    sink2 = torch.empty(blocks * 512, dtype=torch.float32, device=dev)
+    _hip.check(lib.strotss_calib_mfma(2, blocks, 2000, sink2.data_ptr(), clk.data_ptr(), st), "calib")
+    runs = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 60000
+        e0.record()
+        _hip.check(lib.strotss_calib_mfma(2, blocks, iters, sink2.data_ptr(), clk.data_ptr(), st), "calib")
+        e1.record(); e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        c = clk.cpu().numpy().reshape(blocks, 2).astype(np.float64)
+        runs.append((blocks * 8 * iters * 4.0 * 32768.0 / (ms * 1e-3) / 1e12, float(np.median(c[:, 0] / np.maximum(c[:, 1], 1.0)) * 0.1), ms))
+    runs.sort()
+    out["mfma_bf16_lds_random"] = {"tflops": round(runs[2][0], 1), "clock_ghz": round(runs[2][1], 3), "ms": round(runs[2][2], 2),
+                                   "tflops_min_max": [round(runs[0][0], 1), round(runs[-1][0], 1)]}
     nbytes = 256 << 20
     a = torch.empty(nbytes, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
     a.fill_(1)

@@ -241,7 +241,9 @@ int strotss_hypercol_scatter_sorted(const strotss_maps_t* maps, const void* plan
  * Box calibration (bench.py only; nothing on the product path calls these).  strotss_calib_mfma: `blocks` workgroups of
  * four waves, each wave 16 * iters register-only v_mfma_f32_32x32x2_f32 (bf16 == 0: 4096 FLOP each) or
  * v_mfma_f32_32x32x16_bf16 (bf16 != 0: 32768 FLOP each); sink: blocks * 256 floats; clocks: per workgroup
- * {s_memtime ticks, s_memrealtime ticks (100 MHz)} of the loop -> the clock the device held.  strotss_calib_copy: a plain
+ * {s_memtime ticks, s_memrealtime ticks (100 MHz)} of the loop -> the clock the device held.  bf16 == 2: the LOADED loop that
+ * tells boxes apart -- 512-thread workgroups, 4 * iters bf16 MFMAs per wave whose operands are re-read from pseudo-random LDS
+ * data every trip (sink: blocks * 512 floats).  strotss_calib_copy: a plain
  * 16-byte-per-lane streaming copy of `bytes` (a multiple of 16).
  * --------------------------------------------------------------------------------------- */
 int strotss_calib_mfma(int bf16, int blocks, int iters, float* sink, unsigned long long* clocks, void* stream);

@@ -326,6 +326,13 @@ int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, co
                                  int ld, float l, int n_iter, float gscale, float* gpred, float* loss_out,
                                  void* workspace, size_t workspace_bytes, void* stream);
 /* ld = row stride of the feature matrices (strotss_remd_cos_fwd_bwd), 0 for strotss_palette_remd_fwd_bwd */
+/* The same with dist_metrics 'l2' (STROTSS_METRIC_L2) or 'both' (STROTSS_METRIC_BOTH) as the cost (losses.py:27-28): cost matrix
+ * on the f32 MFMA with the distance in its epilogue, the scalings and their reverse sweep as above, the clamp of l2_distance
+ * passing gradient where m >= 1e-6. */
+size_t strotss_sinkhorn_metric_workspace_bytes(int ns, int n, int n_iter);
+int strotss_sinkhorn_metric_fwd_bwd(const float* style, int ns, const float* pred, int n, int d, int ld, int metric, float l,
+                                    int n_iter, float gscale, float* gpred, float* loss_out, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 size_t strotss_remd_workspace_bytes(int ns, int n, int ld);
 /* loss_out[0] = relaxed_emd(style, pred, 'cosine') (losses.py:69-80); gpred += gscale*dloss/dpred.
  * rs = row_inv_norm(style) (constant per scale). */

@@ -757,6 +757,49 @@ __global__ __launch_bounds__(256) void sk_assemble_kernel(const float* __restric
   if (threadIdx.x == 0) q[j] = tot;
 }
 
+// The same assembly for dist_metrics 'l2' / 'both' (losses.py:18-28): M = l2 or cosine + l2; S holds the l2 part with the sign
+// of tf.maximum(m, 1e-6)'s gradient rule (EpiRemdCost).  dM as above, then per metric
+//   l2 part:      w2 = dM * [S > 0] / (D |S|);   W2[j][i] = -w2,  q2[j] = -sum_i w2      (dy_j = y_j sum w2 - sum w2 x_i, r = 1)
+//   cosine part:  W[j][i] = -dM * rs[i],  q[j] = sum_i -dM (1 - cos),  cos = M - |S|     ('both' only)
+__global__ __launch_bounds__(256) void sk_assemble_metric_kernel(const float* __restrict__ Kt, const float* __restrict__ Mt,
+                                                                 const float* __restrict__ S, int ns, int ldm, int T, float l,
+                                                                 const float* __restrict__ U, const float* __restrict__ DA,
+                                                                 const float* __restrict__ V, const float* __restrict__ DB, int n,
+                                                                 const float* __restrict__ rs, float dfeat, int metric,
+                                                                 float* __restrict__ W, float* __restrict__ q,
+                                                                 float* __restrict__ W2, float* __restrict__ q2) {
+  __shared__ float red[4];
+  __shared__ float dbj[64], vpj[64];
+  const int j = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += 256) { dbj[t] = DB[(size_t)t * n + j]; vpj[t] = V[(size_t)t * n + j]; }
+  __syncthreads();
+  const float vT = V[(size_t)T * n + j];
+  float qs = 0.f, qs2 = 0.f;
+  for (int i = threadIdx.x; i < ldm; i += 256) {
+    float w = 0.f, w2 = 0.f;
+    if (i < ns) {
+      const size_t o = (size_t)j * ldm + i;
+      float s = 0.f;
+      for (int t = 0; t < T; ++t) s += U[(size_t)t * ns + i] * dbj[t] + DA[(size_t)t * ns + i] * vpj[t];
+      const float m = Mt[o], sv = S[o], l2 = fabsf(sv);
+      const float dm = Kt[o] * (U[(size_t)(T - 1) * ns + i] * vT * (1.f - l * m) - l * s);
+      w2 = sv > 0.f ? dm / (dfeat * l2) : 0.f;
+      qs2 -= w2;
+      w2 = -w2;
+      if (metric == STROTSS_METRIC_BOTH) {
+        w = -dm;
+        qs += w * (1.f - (m - l2));
+        w *= rs[i];
+      }
+    }
+    W2[(size_t)j * ldm + i] = w2;
+    if (metric == STROTSS_METRIC_BOTH) W[(size_t)j * ldm + i] = w;
+  }
+  const float tot2 = block_sum_256(qs2, red);
+  const float tot = block_sum_256(qs, red);
+  if (threadIdx.x == 0) { q2[j] = tot2; q[j] = tot; }
+}
+
 #define CHK(expr)            \
   do {                       \
     int rc__ = (expr);       \
@@ -975,22 +1018,12 @@ size_t strotss_sinkhorn_workspace_bytes(int ns, int n, int n_iter) {
   return w.off;
 }
 
-int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n, int d,
-                                 int ld, float l, int n_iter, float gscale, float* gpred, float* loss_out,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
-  ST_CHECK_ARG(style && rs && pred && gpred && loss_out && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
-  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
-  ST_CHECK_ARG(l > 0.f && n_iter >= 1 && n_iter <= 64, STROTSS_ERANGE);
-  Workspace w(workspace, workspace_bytes);
-  SinkhornWs s;
-  ST_CHECK_ARG(s.plan(w, ns, n, n_iter), STROTSS_EINVAL);
-  hipStream_t st = (hipStream_t)stream;
-  const int ldm = s.ldm, T = n_iter;
+// Sinkhorn scalings, cost and the reverse sweep on a given pred-major cost matrix s.Mt (n x ldm): fills s.Kt, U, V, DA, DB and
+// loss_out; the caller assembles dM and the chain rule of its metric.
+static int sinkhorn_iterate(SinkhornWs& s, int ns, int n, float l, int T, float* loss_out, hipStream_t st) {
+  const int ldm = s.ldm;
   const float px = 1.0f / (float)ns, py = 1.0f / (float)n;
   const dim3 gcol(cdiv(ns, 64), COL_CHUNKS), gfin(cdiv(ns, 256));
-  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
-  LAUNCH_OK();
-  CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.Mt, ldm, st));          // Mt[j][i] = 1 - <yhat_j, xhat_i>
   hipLaunchKernelGGL(sk_exp_kernel, dim3(min(4096, cdiv((size_t)n * ldm, 256))), dim3(256), 0, st, s.Mt,
                      (size_t)n * ldm, l, s.Kt);
   // v_0 = 1
@@ -1026,17 +1059,79 @@ int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, co
   LAUNCH_OK();
   const int rows = round_up(n, 64);
   if (rows > n) CHK((int)hipMemsetAsync(s.W + (size_t)n * ldm, 0, sizeof(float) * (size_t)(rows - n) * ldm, st));
+  return 0;
+}
+
+int strotss_sinkhorn_cos_fwd_bwd(const float* style, const float* rs, int ns, const float* pred, int n, int d,
+                                 int ld, float l, int n_iter, float gscale, float* gpred, float* loss_out,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(style && rs && pred && gpred && loss_out && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(l > 0.f && n_iter >= 1 && n_iter <= 64, STROTSS_ERANGE);
+  Workspace w(workspace, workspace_bytes);
+  SinkhornWs s;
+  ST_CHECK_ARG(s.plan(w, ns, n, n_iter), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  const int ldm = s.ldm, T = n_iter;
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+  LAUNCH_OK();
+  CHK(st_cosine_distance(pred, s.rp, n, style, rs, ns, ld, s.Mt, ldm, st));          // Mt[j][i] = 1 - <yhat_j, xhat_i>
+  CHK(sinkhorn_iterate(s, ns, n, l, T, loss_out, st));
   hipLaunchKernelGGL(sk_assemble_kernel, dim3(n), dim3(256), 0, st, s.Kt, s.Mt, ns, ldm, T, l, s.U, s.DA, s.V, s.DB, n, rs,
                      s.W, s.q);
   LAUNCH_OK();
   return st_selfsim_bwd_gemm(s.W, ldm, ldm, style, pred, s.rp, s.q, n, ld, gscale, gpred, st);
 }
 
-int strotss_rows_gemm_bwd(const float* W, int ldw, int k, const float* B, const float* x, const float* r, const float* q,
-                          int n, int ld, float g, float* dx, void* stream) {
-  ST_CHECK_ARG(W && B && x && r && q && dx && n > 0 && k > 0 && k <= ldw && ld > 0, STROTSS_EINVAL);
-  ST_CHECK_ARG(ldw % 32 == 0 && ld % 32 == 0, STROTSS_EALIGN);
-  return st_selfsim_bwd_gemm(W, ldw, ldw, B, x, r, q, n, ld, g, dx, (hipStream_t)stream);
+// sinkhorn_knopp with dist_metrics 'l2' / 'both' (losses.py:27-28, 83-105; build-defined like the cosine form): the cost
+// matrix from st_remd_cost (one f32-MFMA product, the distance in its epilogue), the same scalings and reverse sweep, the
+// metric's chain rule in the assembly, one (l2) or two (both) backward GEMMs against the style rows.
+struct SinkhornMetricWs {
+  float *rs, *sp, *ss, *S, *W2, *q2, *ones;
+  bool plan(Workspace& w, int ns, int n) {
+    const int ldm = round_up(ns, 32), rows = round_up(n, 64);
+    rs = w.take<float>(ldm); sp = w.take<float>(round_up(n, 32)); ss = w.take<float>(ldm);
+    S = w.take<float>((size_t)rows * ldm); W2 = w.take<float>((size_t)rows * ldm);
+    q2 = w.take<float>(n); ones = w.take<float>(round_up(n, 32));
+    return w.ok();
+  }
+};
+
+size_t strotss_sinkhorn_metric_workspace_bytes(int ns, int n, int n_iter) {
+  Workspace w = Workspace::planner();
+  SinkhornWs s; SinkhornMetricWs m;
+  s.plan(w, ns, n, n_iter); m.plan(w, ns, n);
+  return w.off;
+}
+
+int strotss_sinkhorn_metric_fwd_bwd(const float* style, int ns, const float* pred, int n, int d, int ld, int metric, float l,
+                                    int n_iter, float gscale, float* gpred, float* loss_out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(style && pred && gpred && loss_out && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
+  ST_CHECK_ARG(metric == STROTSS_METRIC_L2 || metric == STROTSS_METRIC_BOTH, STROTSS_EINVAL);
+  ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
+  ST_CHECK_ARG(l > 0.f && n_iter >= 1 && n_iter <= 64, STROTSS_ERANGE);
+  Workspace w(workspace, workspace_bytes);
+  SinkhornWs s; SinkhornMetricWs m;
+  ST_CHECK_ARG(s.plan(w, ns, n, n_iter) && m.plan(w, ns, n), STROTSS_EINVAL);
+  hipStream_t st = (hipStream_t)stream;
+  const int ldm = s.ldm, T = n_iter;
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, s.rp);
+  hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(ns, 4)), dim3(256), 0, st, style, ns, ld, m.rs);
+  hipLaunchKernelGGL(row_sq_norm_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, pred, n, ld, m.sp);
+  hipLaunchKernelGGL(row_sq_norm_kernel, dim3(cdiv(ns, 4)), dim3(256), 0, st, style, ns, ld, m.ss);
+  hipLaunchKernelGGL(sk_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, m.ones, n, 1.0f);
+  LAUNCH_OK();
+  CHK(st_remd_cost(pred, s.rp, m.sp, n, style, m.rs, m.ss, ns, ld, d, metric, s.Mt, m.S, ldm, st));      // pred-major
+  CHK(sinkhorn_iterate(s, ns, n, l, T, loss_out, st));
+  const int rows = round_up(n, 64);
+  if (rows > n) CHK((int)hipMemsetAsync(m.W2 + (size_t)n * ldm, 0, sizeof(float) * (size_t)(rows - n) * ldm, st));
+  hipLaunchKernelGGL(sk_assemble_metric_kernel, dim3(n), dim3(256), 0, st, s.Kt, s.Mt, m.S, ns, ldm, T, l, s.U, s.DA, s.V, s.DB,
+                     n, m.rs, (float)d, metric, s.W, s.q, m.W2, m.q2);
+  LAUNCH_OK();
+  CHK(st_selfsim_bwd_gemm(m.W2, ldm, ldm, style, pred, m.ones, m.q2, n, ld, gscale, gpred, st));
+  if (metric == STROTSS_METRIC_BOTH) return st_selfsim_bwd_gemm(s.W, ldm, ldm, style, pred, s.rp, s.q, n, ld, gscale, gpred, st);
+  return 0;
 }
 
 size_t strotss_remd_workspace_bytes(int ns, int n, int ld) {

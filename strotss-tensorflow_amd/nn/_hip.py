@@ -103,6 +103,8 @@ SIGNATURES = {
     "strotss_selfsim_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "strotss_sinkhorn_workspace_bytes": (_Z, [_I, _I, _I]),
     "strotss_sinkhorn_cos_fwd_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P, _Z, _P]),
+    "strotss_sinkhorn_metric_workspace_bytes": (_Z, [_I, _I, _I]),
+    "strotss_sinkhorn_metric_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _I, _F, _P, _P, _P, _Z, _P]),
     "strotss_remd_workspace_bytes": (_Z, [_I, _I, _I]),
     "strotss_remd_cos_fwd_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P, _Z, _P]),
     "strotss_selfsim_pred_panels": (_I, [_P, _Z, _I, _I, C.POINTER(_P), C.POINTER(_P)]),

@@ -573,6 +573,15 @@ def sinkhorn_cos_fwd_bwd(style, rs, ns, pred, n, d, l, n_iter, gscale, gpred, lo
           "sinkhorn_cos_fwd_bwd")
 
 
+def sinkhorn_metric_fwd_bwd(style, ns, pred, n, d, metric: str, l, n_iter, gscale, gpred, loss_out):
+    lib = _hip.lib()
+    nb = lib.strotss_sinkhorn_metric_workspace_bytes(ns, n, n_iter)
+    ws = workspaces.get("sinkhorn", nb, pred.device)
+    check(lib.strotss_sinkhorn_metric_fwd_bwd(ptr(style), ns, ptr(pred), n, d, pred.shape[1], REMD_METRICS[metric], float(l),
+                                              int(n_iter), gscale, ptr(gpred), ptr(loss_out), ptr(ws), nb, stream_ptr()),
+          "sinkhorn_metric_fwd_bwd")
+
+
 def palette_remd_fwd_bwd(style, ns, pred, n, gscale, gpred, loss_out, rgb_to_yuv=True, swapped=False):
     l = _hip.lib()
     nb = l.strotss_remd_workspace_bytes(ns, n, 0)

@@ -236,14 +236,17 @@ def sinkhorn_knopp(x: torch.Tensor, y: torch.Tensor, distance: str = 'cosine', l
     (`tf.ones_like(shape)` on a Python tuple), so there is no behaviour to match; this is its evident intent
     (K = exp(-l M), uniform marginals, N_iter alternating scalings from v = 1, cost sum(u * ((K*M) v)), gradient
     through the iterations), pinned by the float64 autograd restatement oracle.strotss_oracle.sinkhorn_knopp.
-    Only the cosine cost is provided on the HIP path."""
+    Every entry of `dist_metrics` is provided (round 4: 'l2' / 'both' through strotss_sinkhorn_metric_fwd_bwd)."""
     if not l > 0:
         raise ValueError("l must be greater than 0")
-    if distance != 'cosine':
-        raise NotImplementedError(f"sinkhorn_knopp(distance={distance!r}): the HIP path covers 'cosine'")
+    if distance not in dist_metrics:
+        raise KeyError(distance)
     _no_grad_side(x, "sinkhorn_knopp(x, y)")
     bx = _buf(x)
     ns, _ = reshape_2d(x).shape
+    if distance != 'cosine':            # 'l2' / 'both' (round 4): cost matrix with the distance in its epilogue, same scalings
+        return _FusedLoss.apply(y, lambda bp, n, dd, g, loss: _ops.sinkhorn_metric_fwd_bwd(bx, ns, bp, n, dd, distance, l, N_iter,
+                                                                                            1.0, g, loss))
     rs = _ops.row_inv_norm(bx, ns)
     return _FusedLoss.apply(y, lambda bp, n, dd, g, loss: _ops.sinkhorn_cos_fwd_bwd(bx, rs, ns, bp, n, dd, l, N_iter, 1.0,
                                                                                      g, loss))

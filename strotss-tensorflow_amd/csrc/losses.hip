@@ -1134,6 +1134,13 @@ int strotss_sinkhorn_metric_fwd_bwd(const float* style, int ns, const float* pre
   return 0;
 }
 
+int strotss_rows_gemm_bwd(const float* W, int ldw, int k, const float* B, const float* x, const float* r, const float* q,
+                          int n, int ld, float g, float* dx, void* stream) {
+  ST_CHECK_ARG(W && B && x && r && q && dx && n > 0 && k > 0 && k <= ldw && ld > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG(ldw % 32 == 0 && ld % 32 == 0, STROTSS_EALIGN);
+  return st_selfsim_bwd_gemm(W, ldw, ldw, B, x, r, q, n, ld, g, dx, (hipStream_t)stream);
+}
+
 size_t strotss_remd_workspace_bytes(int ns, int n, int ld) {
   Workspace w = Workspace::planner();
   RemdWs s;

@@ -617,8 +617,8 @@ def wall_clock_to_output(dev, size=1024, level=5, max_iter=200):
         args = run_strotss.build_parser().parse_args(
             [paths[0], paths[1], "-o", out_path, "--max_size", str(size), "--level", str(level), "--max_iter",
              str(max_iter), "--log_every", str(max_iter), "--weights", wpath])
-        # the CLI draws every step's index set on the host inside the loop (as the reference's traced step does,
-        # strotss_utils.py:83-121): its per-scale rate is what `index_draw` on the bench line quotes
+        # the CLI draws every step's index set inside the step, on the device (as the reference's traced step does,
+        # strotss_utils.py:83-121)
         per_scale, orig = {}, run_strotss._optimise_scale
 
         def timed_scale(eng, scl, *a, **k):
@@ -641,8 +641,8 @@ def wall_clock_to_output(dev, size=1024, level=5, max_iter=200):
             f"(scales 64..{64 << (level - 1)}), incl. VGG build from a weight file (.npz, 59 MB), JPEG decode/encode, per-scale setup, "
             "hipGraph capture",
             "cli_steps_per_sec_by_scale": per_scale,
-            "cli_steps_per_sec_is": "max_iter / wall time of the scale's loop INCLUDING its hipGraph capture and the per-step "
-                                    "host index draws + pinned uploads"}
+            "cli_steps_per_sec_is": "max_iter / wall time of the scale's loop INCLUDING its hipGraph capture (the per-step index "
+                                    "draw is the first kernel of the graph)"}
 
 
 def usable_cores():

@@ -291,14 +291,16 @@ class VGGTrunk:
                                and os.environ.get("STROTSS_PRESCATTER", "1") != "0")
             if self.prescatter:
                 sizes = [a.numel() if i in set(self.taps) else 0 for i, a in enumerate(self.acts)]
-                self._tap_flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+                # (+ the pixel gradient at the end: ONE fill clears everything the single scatter launch adds into)
+                self._tap_flat = torch.zeros(sum(sizes) + 3 * h * w, dtype=torch.float32, device=dev)
                 offs = np.cumsum([0] + sizes)
                 self.grads = [self._tap_flat[offs[i]:offs[i + 1]].view(a.shape) if sizes[i] else torch.empty_like(a)
                               for i, a in enumerate(self.acts)]
+                self._gimg_in_flat = self._tap_flat[sum(sizes):].view(1, h, w, 3)
             else:
                 self.grads = [torch.empty_like(a) for a in self.acts]
             self.gpools = [torch.empty_like(p) for p in self.pools]
-            self.gimg = torch.empty((1, h, w, 3), dtype=torch.float32, device=dev)
+            self.gimg = self._gimg_in_flat if self.prescatter else torch.empty((1, h, w, 3), dtype=torch.float32, device=dev)
         self.img = None
 
     def _can_prescatter(self) -> bool:
@@ -362,7 +364,8 @@ class VGGTrunk:
         last = n_layers - 1
         if pre:
             self._tap_flat.zero_()
-            self.gimg.zero_()
+            if self.gimg.data_ptr() != self._gimg_in_flat.data_ptr():      # (a sharded engine points gimg into its reduce buffer)
+                self.gimg.zero_()
             scatter_all()
             scatter = lambda li: None
         else:

@@ -252,7 +252,7 @@ int strotss_calib_copy(const void* src, void* dst, size_t bytes, void* stream);
 /* ---------------------------------------------------------------------------------------
  * Sample coordinates drawn on the device  (Sampling._make_indices, nn/strotss_utils.py:83-121; the reference draws
  * them inside the traced train_step, run_strotss.py:136 / 115).  Region r (one workgroup each) reads its draw number
- * t = counter[r], draws the grid offsets (k = 0 rows, 1 columns:  philox4x32-10(ctr = (k, 1, t, 0), key = seed)[0] mod
+ * t = counter[r], draws the grid offsets (k = 0 rows, 1 columns:  philox4x32-10(ctr = (0, 1, t, 0), key = seed)[k] mod
  * step), lists the candidates (off_x + a*step_x, off_y + b*step_y) in tf.meshgrid('xy') order (a fastest), keeps those
  * whose mask byte is nonzero (mask[r] == NULL: all), gives position j of the kept list the shuffle key
  * philox(ctr = (j >> 2, 0, t, 0))[j & 3], writes the min(sample_size, kept) positions with the smallest (key, j) in
@@ -273,6 +273,7 @@ typedef struct strotss_draw_t {
   float* idx[STROTSS_DRAW_MAX_REGIONS];                  /* (sample_size, 2) float32               */
   unsigned* counter;              /* n_regions draw numbers in device memory                       */
   int* n_out;                     /* n_regions counts, or NULL                                     */
+  int debug_flags;                /* bit 0: take the kernel's general selection path (tests)       */
 } strotss_draw_t;
 int strotss_index_draw_max_candidates(int h, int w, int step_x, int step_y);
 int strotss_index_draw(const strotss_draw_t* d, void* stream);

@@ -4,7 +4,7 @@
 //
 // The random numbers are COUNTER-BASED (Philox4x32-10, the generator family behind tf.random.Generator; not TF's stream, which
 // cannot be reproduced without TF): draw number t of a stream with key (seed_lo, seed_hi) uses
-//     offset k (0: rows, 1: columns)     philox(ctr = (k, 1, t, 0))[0] mod step
+//     offset k (0: rows, 1: columns)     philox(ctr = (0, 1, t, 0))[k] mod step
 //     shuffle key of position j          philox(ctr = (j >> 2, 0, t, 0))[j & 3]        (j = position in the FILTERED list)
 // and "shuffle, take the first n" = the n positions with the smallest (key, j), in ascending order.  nn/rand.py:PhiloxStream
 // is the host twin: a NumPy-Generator look-alike (integers / permutation) that the oracle's make_indices consumes
@@ -64,10 +64,9 @@ __global__ __launch_bounds__(DRAW_T) void index_draw_kernel(strotss_draw_t d) {
   const unsigned t = d.counter[r];
   const unsigned char* mask = d.mask[r];
   unsigned o4[4];
-  philox4x32_10(0u, 1u, t, 0u, d.seed_lo, d.seed_hi, o4);
+  philox4x32_10(0u, 1u, t, 0u, d.seed_lo, d.seed_hi, o4);      // words 0, 1 of ONE block: the row and the column offset
   const int off_x = (int)(o4[0] % (unsigned)d.step_x);
-  philox4x32_10(1u, 1u, t, 0u, d.seed_lo, d.seed_hi, o4);
-  const int off_y = (int)(o4[0] % (unsigned)d.step_y);
+  const int off_y = (int)(o4[1] % (unsigned)d.step_y);
   const int nx = (d.h - off_x + d.step_x - 1) / d.step_x, ny = (d.w - off_y + d.step_y - 1) / d.step_y;
   const int M = nx * ny;                                   // host guarantees <= DRAW_MAXC
   // wave wv owns candidates [wv * seg, (wv + 1) * seg), seg a multiple of 64; lane l takes c = base + i * 64 + l
@@ -130,12 +129,14 @@ __global__ __launch_bounds__(DRAW_T) void index_draw_kernel(strotss_draw_t d) {
     }
   }
   __syncthreads();
-  // ---- radix select: the key T of rank n_out (1-based) among the valid candidates
+  // ---- selection of the n_out smallest (key, candidate) pairs.  Level 0 of a radix select over the top 11 key bits finds the
+  // bin that holds the n_out-th smallest key.  FAST PATH (that bin holds <= 1024 candidates: always, for random keys -- its
+  // expected load is candidates / 2048): everything below the bin is in, the bin's own candidates are ranked against each
+  // other by (key, candidate) and the first `need` of them join.  GENERAL PATH (kept exact for any key distribution; forced by
+  // debug_flags bit 0 so that the tests run it): two more radix levels (11 + 10 bits) give the threshold key T, ties at T are
+  // taken in position order.
   unsigned prefix = 0, pmask = 0, need = (unsigned)n_out;
-#pragma unroll
-  for (int level = 0; level < 3; ++level) {
-    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
-    const unsigned nb = level == 2 ? 1024u : 2048u;
+  auto radix_level = [&](int shift, unsigned nb) {
     for (int i = tid; i < DRAW_BINS; i += DRAW_T) hist[i] = 0u;
     __syncthreads();
     for (int i = 0; i < trips; ++i) {
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(DRAW_T) void index_draw_kernel(strotss_draw_t d) {
       const bool second = need > excl + h0;
       sh[20] = (unsigned)(2 * tid + (second ? 1 : 0));
       sh[21] = excl + (second ? h0 : 0u);
+      sh[22] = second ? h1 : h0;                                           // the bin's own count
     }
     __syncthreads();
     const unsigned bin = sh[20], before = sh[21];
@@ -170,31 +172,54 @@ __global__ __launch_bounds__(DRAW_T) void index_draw_kernel(strotss_draw_t d) {
     prefix |= bin << shift;
     pmask |= (nb - 1u) << shift;
     __syncthreads();
-  }
-  const unsigned T = prefix, ties_needed = need;                           // candidates with key == T: the first `need` by position
-  // ---- ties at the threshold, in position order
-  unsigned wave_ties = 0;
-  for (int i = 0; i < trips; ++i) {
-    const int c = c_begin + i * 64 + lane;
-    const bool tie = c < M && ((vbits[c >> 5] >> (c & 31)) & 1u) && keys[c] == T;
-    wave_ties += (unsigned)__popcll(__ballot(tie));
-  }
-  unsigned all_ties;
-  unsigned tie_run = wave_totals_scan(wave_ties, sh, &all_ties);
-  if (tid == 0) sh[24] = 0u;
+  };
+  radix_level(21, 2048u);
+  const unsigned bin0 = prefix >> 21, cnt0 = sh[22];
+  if (tid == 0) { sh[24] = 0u; sh[25] = 0u; }
   __syncthreads();
-  for (int i = 0; i < trips; ++i) {
-    const int c = c_begin + i * 64 + lane;
-    bool valid = c < M && ((vbits[c >> 5] >> (c & 31)) & 1u);
-    const unsigned k = valid ? keys[c] : 0u;
-    const bool tie = valid && k == T;
-    const unsigned long long b = __ballot(tie);
-    bool take = valid && k < T;
-    if (tie) take = tie_run + (unsigned)__popcll(b & lt_mask) < ties_needed;
-    tie_run += (unsigned)__popcll(b);
-    if (take) {
-      const unsigned slot = atomicAdd(&sh[24], 1u);
-      list[slot] = ((unsigned long long)k << 32) | (unsigned)c;
+  if (cnt0 <= (unsigned)DRAW_T && !(d.debug_flags & 1)) {
+    unsigned long long* cont = reinterpret_cast<unsigned long long*>(hist);      // the histogram is dead: 1024 x 8 bytes
+    for (int i = 0; i < trips; ++i) {
+      const int c = c_begin + i * 64 + lane;
+      if (c < M && ((vbits[c >> 5] >> (c & 31)) & 1u)) {
+        const unsigned k = keys[c], top = k >> 21;
+        const unsigned long long comp = ((unsigned long long)k << 32) | (unsigned)c;
+        if (top < bin0) list[atomicAdd(&sh[24], 1u)] = comp;
+        else if (top == bin0) cont[atomicAdd(&sh[25], 1u)] = comp;
+      }
+    }
+    __syncthreads();
+    if ((unsigned)tid < cnt0) {
+      const unsigned long long me = cont[tid];
+      unsigned rank = 0;
+      for (unsigned q = 0; q < cnt0; ++q) rank += cont[q] < me ? 1u : 0u;
+      if (rank < need) list[atomicAdd(&sh[24], 1u)] = me;
+    }
+  } else {
+    radix_level(10, 2048u);
+    radix_level(0, 1024u);
+    const unsigned T = prefix, ties_needed = need;                         // candidates with key == T: the first `need` by position
+    unsigned wave_ties = 0;
+    for (int i = 0; i < trips; ++i) {
+      const int c = c_begin + i * 64 + lane;
+      const bool tie = c < M && ((vbits[c >> 5] >> (c & 31)) & 1u) && keys[c] == T;
+      wave_ties += (unsigned)__popcll(__ballot(tie));
+    }
+    unsigned all_ties;
+    unsigned tie_run = wave_totals_scan(wave_ties, sh, &all_ties);
+    for (int i = 0; i < trips; ++i) {
+      const int c = c_begin + i * 64 + lane;
+      bool valid = c < M && ((vbits[c >> 5] >> (c & 31)) & 1u);
+      const unsigned k = valid ? keys[c] : 0u;
+      const bool tie = valid && k == T;
+      const unsigned long long b = __ballot(tie);
+      bool take = valid && k < T;
+      if (tie) take = tie_run + (unsigned)__popcll(b & lt_mask) < ties_needed;
+      tie_run += (unsigned)__popcll(b);
+      if (take) {
+        const unsigned slot = atomicAdd(&sh[24], 1u);
+        list[slot] = ((unsigned long long)k << 32) | (unsigned)c;
+      }
     }
   }
   __syncthreads();

@@ -43,7 +43,7 @@ class DrawT(C.Structure):
     _fields_ = [("h", C.c_int), ("w", C.c_int), ("step_x", C.c_int), ("step_y", C.c_int), ("sample_size", C.c_int),
                 ("n_regions", C.c_int), ("seed_lo", C.c_uint), ("seed_hi", C.c_uint), ("counter_stride", C.c_uint),
                 ("mask", C.c_void_p * MAX_DRAW_REGIONS), ("idx", C.c_void_p * MAX_DRAW_REGIONS),
-                ("counter", C.c_void_p), ("n_out", C.c_void_p)]
+                ("counter", C.c_void_p), ("n_out", C.c_void_p), ("debug_flags", C.c_int)]
 
 
 class PyramidT(C.Structure):

@@ -379,7 +379,7 @@ def hypercol_scatter_sorted(maps_t, plan: torch.Tensor, n: int, gfeat: torch.Ten
 
 # ------------------------------------------------------------------ losses
 def index_draw(h: int, w: int, sample_size: int, seed: int, counters: torch.Tensor, out_idx, masks=None, n_out=None,
-               stride=None) -> None:
+               stride=None, general_path: bool = False) -> None:
     """One launch of strotss_index_draw (csrc/draw.hip; reference: Sampling._make_indices, strotss_utils.py:83-121): region r's
     next draw of its stream (draw number counters[r], advanced by `stride` afterwards) -> out_idx[r] (sample_size, 2) float32.
     masks: per region a (h, w) uint8 device tensor at THIS scale (nonzero = keep) or None; n_out: int32 (R,) or None.
@@ -402,6 +402,7 @@ def index_draw(h: int, w: int, sample_size: int, seed: int, counters: torch.Tens
             assert m.is_cuda and m.dtype == torch.uint8 and m.is_contiguous() and tuple(m.shape) == (int(h), int(w))
             d.mask[r] = m.data_ptr()
     d.counter = counters.data_ptr()
+    d.debug_flags = 1 if general_path else 0     # (tests: the selection path that is exact for ANY key distribution)
     if n_out is not None:
         assert n_out.dtype == torch.int32 and n_out.numel() >= R and n_out.is_cuda
         d.n_out = n_out.data_ptr()

@@ -47,7 +47,7 @@ class PhiloxStream:
 
     One *draw* = one call of make_indices (strotss_utils.py:83-121): up to two `integers` calls (the grid offsets) followed by
     exactly one `permutation`, which ends the draw (t += 1).
-        integers(0, n), k-th call of the draw   philox(ctr = (k, 1, t, 0))[0] mod n
+        integers(0, n), k-th call of the draw   philox(ctr = (0, 1, t, 0))[k] mod n
         permutation(m)                          order of the positions j < m by (philox(ctr = (j >> 2, 0, t, 0))[j & 3], j)
     """
 
@@ -65,7 +65,8 @@ class PhiloxStream:
             low, high = 0, low
         n = int(high) - int(low)
         assert n > 0
-        v = int(philox4x32_10(self._k, 1, self.t & 0xFFFFFFFF, 0, *self.key)[0])
+        assert self._k < 4, "a draw has at most four offset words (make_indices uses two)"
+        v = int(philox4x32_10(0, 1, self.t & 0xFFFFFFFF, 0, *self.key)[self._k])
         self._k += 1
         return int(low) + v % n
 

@@ -131,7 +131,9 @@ def test_device_index_draw_equals_the_oracle_draw_element_for_element(h, w):
         out = [torch.full((n, 2), -7.0, device="cuda") for _ in range(R)]
         twin = RAND.PhiloxStream(seed, t0)
         for step in range(3):
-            _ops.index_draw(h, w, n, seed, counters, out, dev_masks, n_out)
+            # (step 1 takes the kernel's GENERAL selection path -- three radix levels + ties in position order, exact for any
+            # key distribution -- instead of the fast one: both must give the oracle's coordinates)
+            _ops.index_draw(h, w, n, seed, counters, out, dev_masks, n_out, general_path=(step == 1))
             torch.cuda.synchronize()
             assert counters.tolist() == [t0 + (step + 1) * R + r for r in range(R)]
             for r, k in enumerate(regions):

@@ -200,6 +200,26 @@ def box_calibration(dev):
     runs.sort()
     out["mfma_bf16_lds_random"] = {"tflops": round(runs[2][0], 1), "clock_ghz": round(runs[2][1], 3), "ms": round(runs[2][2], 2),
                                    "tflops_min_max": [round(runs[0][0], 1), round(runs[-1][0], 1)]}
+    # dependent-load latency in the L2 (2 MB chain), the Infinity Cache (64 MB) and HBM (1 GB): ns per hop, 64 chasers
+    lat = {}
+    g = torch.Generator().manual_seed(1)
+    for name, n_el, steps in (("l2_2MB", 1 << 15, 20000), ("mall_64MB", 1 << 20, 10000), ("hbm_1GB", 1 << 24, 5000)):
+        perm = torch.randperm(n_el, generator=g)
+        nxt = torch.empty(n_el, dtype=torch.int64)
+        nxt[perm] = perm.roll(-1)                                    # one cycle through all elements
+        buf = torch.zeros(n_el * 16, dtype=torch.int32)
+        buf[::16] = nxt.to(torch.int32)
+        dbuf = buf.to(dev)
+        sink3 = torch.zeros(64, dtype=torch.int32, device=dev)
+        clk3 = torch.zeros(128, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            _hip.check(lib.strotss_calib_chase(dbuf.data_ptr(), n_el // 64, 64, steps, sink3.data_ptr(), clk3.data_ptr(), st), "chase")
+        torch.cuda.synchronize()
+        c = clk3.cpu().numpy().reshape(64, 2).astype(np.float64)
+        lat[name] = {"ns_per_hop": round(float(np.median(c[:, 1])) * 10.0 / steps, 1),
+                     "cycles_per_hop": round(float(np.median(c[:, 0])) / steps, 1)}
+        del dbuf
+    out["latency"] = lat
     nbytes = 256 << 20
     a = torch.empty(nbytes, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
     a.fill_(1)

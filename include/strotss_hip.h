@@ -248,6 +248,11 @@ int strotss_hypercol_scatter_sorted(const strotss_maps_t* maps, const void* plan
  * --------------------------------------------------------------------------------------- */
 int strotss_calib_mfma(int bf16, int blocks, int iters, float* sink, unsigned long long* clocks, void* stream);
 int strotss_calib_copy(const void* src, void* dst, size_t bytes, void* stream);
+/* dependent-load latency: workgroup b starts at element b * start_stride of `next` (a random cycle over n elements, element i
+ * at next[16 * i]: 64-byte stride) and follows `steps` links with one lane; clocks[2b], clocks[2b + 1] = s_memtime /
+ * s_memrealtime ticks of its chase */
+int strotss_calib_chase(const unsigned* next, unsigned start_stride, int blocks, int steps, unsigned* sink,
+                        unsigned long long* clocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sample coordinates drawn on the device  (Sampling._make_indices, nn/strotss_utils.py:83-121; the reference draws

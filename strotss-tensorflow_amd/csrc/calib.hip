@@ -96,6 +96,20 @@ __global__ __launch_bounds__(512) void calib_mfma_lds_kernel(float* __restrict__
   if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// Dependent-load latency: one lane per workgroup chases `steps` links of a pre-built random cycle (next[i] = index of the
+// following element, 64-byte stride so that every hop is a new line).  Footprints of 2 MB / 64 MB / 1 GB put the chain in the L2,
+// the Infinity Cache and HBM.  clk[b] = s_memtime ticks of workgroup b's chase.
+__global__ __launch_bounds__(64) void calib_chase_kernel(const unsigned* __restrict__ next, unsigned start_stride, int steps,
+                                                         unsigned* __restrict__ sink, unsigned long long* __restrict__ clk) {
+  if (threadIdx.x != 0) return;
+  unsigned i = blockIdx.x * start_stride;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int s = 0; s < steps; ++s) i = __builtin_nontemporal_load(next + (size_t)i * 16);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  sink[blockIdx.x] = i;
+  clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0;
+}
+
 // 16 bytes per lane, grid-stride: a plain streaming copy
 __global__ __launch_bounds__(256) void calib_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n16) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
@@ -113,6 +127,14 @@ int strotss_calib_mfma(int bf16, int blocks, int iters, float* sink, unsigned lo
   }
   if (bf16) hipLaunchKernelGGL(calib_mfma_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sink, iters, clocks);
   else hipLaunchKernelGGL(calib_mfma_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sink, iters, clocks);
+  ST_LAUNCH_RET();
+}
+
+int strotss_calib_chase(const unsigned* next, unsigned start_stride, int blocks, int steps, unsigned* sink,
+                        unsigned long long* clocks, void* stream) {
+  ST_CHECK_ARG(next && sink && clocks && blocks > 0 && blocks <= 4096 && steps > 0, STROTSS_EINVAL);
+  hipLaunchKernelGGL(calib_chase_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, next, start_stride, steps, sink,
+                     clocks);
   ST_LAUNCH_RET();
 }
 

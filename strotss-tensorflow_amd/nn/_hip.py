@@ -91,6 +91,7 @@ SIGNATURES = {
     "strotss_hypercol_scatter_sorted": (_I, [C.POINTER(MapsT), _P, _I, _P, _I, _I, _I, _I, _P]),
     "strotss_calib_mfma": (_I, [_I, _I, _I, _P, _P, _P]),
     "strotss_calib_copy": (_I, [_P, _P, _Z, _P]),
+    "strotss_calib_chase": (_I, [_P, C.c_uint, _I, _I, _P, _P, _P]),
     "strotss_index_draw_max_candidates": (_I, [_I, _I, _I, _I]),
     "strotss_index_draw": (_I, [C.POINTER(DrawT), _P]),
     "strotss_row_inv_norm": (_I, [_P, _I, _I, _P, _P]),

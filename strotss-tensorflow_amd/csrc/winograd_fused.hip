@@ -49,6 +49,17 @@ __device__ long long fused_prof[2][64][8];
 #else
 #define ABL_R(x) x
 #endif
+// finer ablations of the patch path: only its global loads / only its LDS stores compiled out
+#ifdef FUSED_NO_RAW_LOAD
+#define ABL_RL(x) do {} while (0)
+#else
+#define ABL_RL(x) x
+#endif
+#ifdef FUSED_NO_RAW_STORE
+#define ABL_RS(x) do {} while (0)
+#else
+#define ABL_RS(x) x
+#endif
 
 constexpr int F_TR = 4, F_TC = 8;                  // Winograd tiles per work item: rows x cols
 constexpr int F_TILES = F_TR * F_TC;               // 32 = M of the MFMA tile
@@ -283,9 +294,9 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
       load_u(r1.g, k1, BNEXT);                                                                                \
       /* the patch loads (32 cache lines per wave instruction) go here, not to the phase start: 24 of them */ \
       /* queued in the CU's address unit right after the barrier stall every wave behind them             */ \
-      ABL_R(load_raw(r3, k3, SLOAD));                                                                         \
+      ABL_R(ABL_RL(load_raw(r3, k3, SLOAD)));                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
-      ABL_R(store_raw(Rb + PAR * F_RAW, okm2, SSTORE));                                                       \
+      ABL_R(ABL_RS(store_raw(Rb + PAR * F_RAW, okm2, SSTORE)));                                               \
       PROF(4);                                                                                                \
       __syncthreads();                                                                                        \
       PROF(5);                                                                                                \

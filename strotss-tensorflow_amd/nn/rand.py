@@ -71,14 +71,30 @@ class PhiloxStream:
         return int(low) + v % n
 
     def keys(self, m: int) -> np.ndarray:
-        j = np.arange(m, dtype=np.uint64)
-        out = philox4x32_10(j >> np.uint64(2), 0, self.t & 0xFFFFFFFF, 0, *self.key)
-        lane = (j & np.uint64(3)).astype(np.int64)
-        return np.stack(out, axis=0)[lane, np.arange(m)]
+        """shuffle keys of the positions 0..m-1 of this draw: one Philox block per four positions"""
+        q = np.arange((m + 3) // 4, dtype=np.uint64)
+        out = philox4x32_10(q, 0, self.t & 0xFFFFFFFF, 0, *self.key)
+        return np.stack(out, axis=1).reshape(-1)[:m]
 
     def permutation(self, m):
         m = int(m)
         order = np.lexsort((np.arange(m), self.keys(m)))            # by key, ties by position
+        self.t += 1
+        self._k = 0
+        return order
+
+    def permutation_head(self, m, k):
+        """permutation(m)[:k] without sorting all m keys (the style draw of a 1024-px scale shuffles a million positions to
+        keep 1024: strotss_utils.py:99-120): the k smallest (key, position) pairs, in order.  Ends the draw like permutation."""
+        m, k = int(m), int(k)
+        if k >= m:
+            return self.permutation(m)
+        keys = self.keys(m)
+        T = np.partition(keys, k - 1)[k - 1]
+        below = np.flatnonzero(keys < T)
+        ties = np.flatnonzero(keys == T)[:k - below.size]            # flatnonzero is ascending: ties in position order
+        sel = np.concatenate([below, ties])
+        order = sel[np.lexsort((sel, keys[sel]))]
         self.t += 1
         self._k = 0
         return order

@@ -86,7 +86,10 @@ def make_indices_np(h: int, w: int, bilinear_sampling: bool, sample_size: int, r
     ret = np.stack([XX.reshape(-1), YY.reshape(-1)], axis=1)
     if mask_hw is not None:
         ret = ret[mask_hw[ret[:, 0], ret[:, 1]]]
-    ret = ret[rng.permutation(ret.shape[0])][:sample_size]
+    if hasattr(rng, "permutation_head"):                # PhiloxStream: the same first `sample_size` entries, without the full sort
+        ret = ret[rng.permutation_head(ret.shape[0], sample_size)]
+    else:
+        ret = ret[rng.permutation(ret.shape[0])][:sample_size]
     return ret.astype(np.float32)
 
 

@@ -379,19 +379,21 @@ size_t strotss_remd_metric_workspace_bytes(int ns, int n);
 int strotss_remd_metric_fwd_bwd(const float* style, int ns, const float* pred, int n, int d, int ld, int metric,
                                 float gscale, float* gpred, float* loss_out, int flags, void* workspace,
                                 size_t workspace_bytes, void* stream);
-/* The three feature-space losses of one train step on the same prediction rows (run_strotss.py:131-142) in ONE call:
+/* The four loss terms of one train step on the same prediction rows (run_strotss.py:131-142, 33-40) in ONE call:
  * loss_content[0] = self_similarity(pred, content), loss_moment[0] = moment_matching(style, pred) (style side given by
  * strotss_moment_stats), loss_remd[0] = relaxed_emd(style, pred) (cosine; style_inv_norm / style_panels =
- * strotss_row_inv_norm_x3(style)), gpred += g_content * d(content)/d(pred) + g_moment * ... + g_remd * ....  Bit for bit
- * strotss_selfsim_fwd_bwd, strotss_moment_fwd_bwd and strotss_remd_cos_fwd_bwd_panels called in this order; the three forward
- * GEMMs (two symmetric cost matrices, covariance, prediction x style cost matrix) share ONE launch.  bf16x3 core only:
- * STROTSS_EINVAL when STROTSS_X3 / _COST / _MOMENT switch it off (take the separate entry points). */
+ * strotss_row_inv_norm_x3(style)), loss_palette[0] = relaxed_emd(yuv(style[:, :3]), yuv(pred[:, :3]), 'both'),
+ * gpred += g_content * d(content)/d(pred) + g_moment * ... + g_remd * ... + g_palette * ....  Bit for bit
+ * strotss_selfsim_fwd_bwd, strotss_moment_fwd_bwd, strotss_remd_cos_fwd_bwd_panels and strotss_palette_remd_fwd_bwd called in
+ * this order; the three forward GEMMs (two symmetric cost matrices, covariance, prediction x style cost matrix) share ONE
+ * launch, the prologues of all four terms another, row statistics and moment scalars a third: 13 launches instead of 21.
+ * bf16x3 core only: STROTSS_EINVAL when STROTSS_X3 / _COST / _MOMENT switch it off (take the separate entry points). */
 size_t strotss_step_losses_workspace_bytes(int ns, int n, int ld);
 int strotss_step_losses_fwd_bwd(const float* pred, const float* content, int n, int d, int ld, const float* style,
                                 const float* style_inv_norm, const void* style_panels, int ns, const float* style_mean,
-                                const float* style_cov, float g_content, float g_moment, float g_remd, float* gpred,
-                                float* loss_content, float* loss_moment, float* loss_remd, void* workspace,
-                                size_t workspace_bytes, void* stream);
+                                const float* style_cov, float g_content, float g_moment, float g_remd, float g_palette,
+                                float* gpred, float* loss_content, float* loss_moment, float* loss_remd, float* loss_palette,
+                                void* workspace, size_t workspace_bytes, void* stream);
 size_t strotss_moment_workspace_bytes(int n, int ld);
 /* style side of moment_matching, once per scale: mean_out(ld), cov_out(ld,ld) = biased covariance */
 int strotss_moment_stats(const float* x, int n, int d, int ld, float* mean_out, float* cov_out,

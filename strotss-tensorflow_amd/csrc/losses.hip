@@ -42,12 +42,12 @@ __global__ __launch_bounds__(256) void row_sq_norm_kernel(const float* __restric
 // The same pass also writing the row as x3 panels (mfma_x3.h: three bf16 planes per value, K-blocked) for the
 // bf16x3 cost-matrix GEMM.  r may be NULL (norms already known).  ld % 32 == 0.
 // blockIdx.y = 1 selects a second matrix (x1, n1, r1, panels1): both feature matrices of a loss in one launch.
-__global__ __launch_bounds__(256) void row_inv_norm_x3_kernel(const float* __restrict__ x, int n, int ld,
+__device__ __forceinline__ void row_inv_norm_x3_kernel_body(const float* __restrict__ x, int n, int ld,
                                                               float* __restrict__ r, __bf16* __restrict__ panels,
                                                               const float* __restrict__ x1, int n1,
-                                                              float* __restrict__ r1, __bf16* __restrict__ panels1) {
-  if (blockIdx.y) { x = x1; n = n1; r = r1; panels = panels1; }
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                              float* __restrict__ r1, __bf16* __restrict__ panels1, const int bx, const int by) {
+  if (by) { x = x1; n = n1; r = r1; panels = panels1; }
+  const int row = bx * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
   const float* p = x + (size_t)row * ld;
@@ -61,6 +61,12 @@ __global__ __launch_bounds__(256) void row_inv_norm_x3_kernel(const float* __res
     s = wave_sum(s);
     if (lane == 0) r[row] = 1.0f / sqrtf(fmaxf(s, 1e-12f));
   }
+}
+__global__ __launch_bounds__(256) void row_inv_norm_x3_kernel(const float* __restrict__ x, int n, int ld,
+                                                              float* __restrict__ r, __bf16* __restrict__ panels,
+                                                              const float* __restrict__ x1, int n1,
+                                                              float* __restrict__ r1, __bf16* __restrict__ panels1) {
+  row_inv_norm_x3_kernel_body(x, n, ld, r, panels, x1, n1, r1, panels1, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // s[i] = sum_{j<n} D[i,j]
@@ -84,13 +90,13 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ 
 // Out: isx[j] = 1/max(sx_j, 1e-12), isy[j], t[j], lossrow[j] -- all the backward needs of row j:
 //   dL/dDx[:,j] = Q[j,:] = (S' - t_j) * isx_j   is recomputed where it is used (selfsim_sym_kernel), never stored.
 #define SS_REG 4
-__global__ __launch_bounds__(256) void selfsim_rowstat_kernel(const float* __restrict__ Dx,
+__device__ __forceinline__ void selfsim_rowstat_kernel_body(const float* __restrict__ Dx,
                                                               const float* __restrict__ Dy, int n, int ldc,
                                                               float sscale, float* __restrict__ isx_out,
                                                               float* __restrict__ isy_out, float* __restrict__ t_out,
-                                                              float* __restrict__ lossrow) {
+                                                              float* __restrict__ lossrow, const int bx, const int by) {
   __shared__ float red[4];
-  const int j = blockIdx.x;
+  const int j = bx;
   const float* px = Dx + (size_t)j * ldc;
   const float* py = Dy + (size_t)j * ldc;
   float vx[SS_REG], vy[SS_REG];
@@ -126,6 +132,13 @@ __global__ __launch_bounds__(256) void selfsim_rowstat_kernel(const float* __res
   t = block_sum_256(t, red);
   if (!(sxr >= 1e-12f)) t = 0.f;
   if (threadIdx.x == 0) { isx_out[j] = isx; isy_out[j] = isy; t_out[j] = t; lossrow[j] = l; }
+}
+__global__ __launch_bounds__(256) void selfsim_rowstat_kernel(const float* __restrict__ Dx,
+                                                              const float* __restrict__ Dy, int n, int ldc,
+                                                              float sscale, float* __restrict__ isx_out,
+                                                              float* __restrict__ isy_out, float* __restrict__ t_out,
+                                                              float* __restrict__ lossrow) {
+  selfsim_rowstat_kernel_body(Dx, Dy, n, ldc, sscale, isx_out, isy_out, t_out, lossrow, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // M[i,j] = -(Q[i,j] + Q[j,i]) with Q[i,j] = (sign(Dx[i,j] isx_i - Dy[i,j] isy_i) sscale - t_i) isx_i and, the cosine
@@ -436,12 +449,12 @@ __global__ __launch_bounds__(256) void remd_generic_bwd_kernel(
 
 // ---------------------------------------------------------------- palette (D = 3, pure VALU)
 // yuv[i] = (Y, U, V, r) with r the inverse norm of the YUV vector  (strotss_utils.py:166-167)
-__global__ __launch_bounds__(256) void palette_prepare_kernel(const float* __restrict__ feat, int n, int ld,
+__device__ __forceinline__ void palette_prepare_kernel_body(const float* __restrict__ feat, int n, int ld,
                                                               f32x4* __restrict__ yuv, int convert,
                                                               const float* __restrict__ feat1, int n1,
-                                                              f32x4* __restrict__ yuv1) {
-  if (blockIdx.y) { feat = feat1; n = n1; yuv = yuv1; }    // second matrix (style and prediction in one launch)
-  const int i = blockIdx.x * 256 + threadIdx.x;
+                                                              f32x4* __restrict__ yuv1, const int bx, const int by) {
+  if (by) { feat = feat1; n = n1; yuv = yuv1; }    // second matrix (style and prediction in one launch)
+  const int i = bx * 256 + threadIdx.x;
   if (i >= n) return;
   const float* p = feat + (size_t)i * ld;
   const float R = p[0], G = p[1], B = p[2];
@@ -454,6 +467,12 @@ __global__ __launch_bounds__(256) void palette_prepare_kernel(const float* __res
   const float ss = Y * Y + U * U + V * V;
   f32x4 o = {Y, U, V, 1.0f / sqrtf(fmaxf(ss, 1e-12f))};
   yuv[i] = o;
+}
+__global__ __launch_bounds__(256) void palette_prepare_kernel(const float* __restrict__ feat, int n, int ld,
+                                                              f32x4* __restrict__ yuv, int convert,
+                                                              const float* __restrict__ feat1, int n1,
+                                                              f32x4* __restrict__ yuv1) {
+  palette_prepare_kernel_body(feat, n, ld, yuv, convert, feat1, n1, yuv1, (int)blockIdx.x, (int)blockIdx.y);
 }
 __device__ __forceinline__ void palette_pair(const f32x4 a, const f32x4 b, float& ccos, float& m) {
   const float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
@@ -549,19 +568,23 @@ __global__ __launch_bounds__(64) void palette_bwd_kernel(
 // ---------------------------------------------------------------- moment matching helpers
 // mean[c] = (1/n) sum_{i<n} y[i,c] in two stages (grid (ld/64, COL_CHUNKS) partial sums, then a fixed-order
 // combine), so the column reduction uses the whole chip.
-__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ y, int n, int ld,
-                                                              float* __restrict__ psum) {
+__device__ __forceinline__ void col_sum_partial_kernel_body(const float* __restrict__ y, int n, int ld,
+                                                              float* __restrict__ psum, const int bx, const int by) {
   __shared__ float sm[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + c;
+  const int col = bx * 64 + c;
   const int per = (n + COL_CHUNKS - 1) / COL_CHUNKS;
-  const int i0 = blockIdx.y * per, i1 = min(n, i0 + per);
+  const int i0 = by * per, i1 = min(n, i0 + per);
   float a = 0.f;
   if (col < ld)
     for (int i = i0 + g; i < i1; i += 4) a += y[(size_t)i * ld + col];
   sm[g][c] = a;
   __syncthreads();
-  if (g == 0 && col < ld) psum[(size_t)blockIdx.y * ld + col] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+  if (g == 0 && col < ld) psum[(size_t)by * ld + col] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+}
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ y, int n, int ld,
+                                                              float* __restrict__ psum) {
+  col_sum_partial_kernel_body(y, n, ld, psum, (int)blockIdx.x, (int)blockIdx.y);
 }
 __global__ __launch_bounds__(256) void col_mean_final_kernel(const float* __restrict__ psum, int n, int ld,
                                                              float* __restrict__ mean) {
@@ -592,15 +615,15 @@ __global__ __launch_bounds__(256) void center_kernel(const float* __restrict__ y
 // K = ld features: the backward product's A) and Pt (rows = ld features, K = npad samples, zeros for i >= n: both
 // operands of the covariance).  One 32 x 32 tile per workgroup, transposed through LDS; grid (ld/32, npad/32).
 // mean == NULL: no centring; Pc == NULL: transposed panels only (the self-similarity backward's B operand).
-__global__ __launch_bounds__(256) void center_x3_kernel(const float* __restrict__ y, int n, int npad, int ld,
+__device__ __forceinline__ void center_x3_kernel_body(const float* __restrict__ y, int n, int npad, int ld,
                                                         const float* __restrict__ mean, __bf16* __restrict__ Pc,
-                                                        __bf16* __restrict__ Pt, const float* __restrict__ psum = nullptr,
-                                                        float* __restrict__ mean_out = nullptr) {
+                                                        __bf16* __restrict__ Pt, const float* __restrict__ psum,
+                                                        float* __restrict__ mean_out, const int bx, const int by) {
   // psum != NULL: the column means come from col_sum_partial_kernel's partial sums here (the arithmetic of
   // col_mean_final_kernel, chunk order and division included -- one launch less), block row 0 also stores them
   __shared__ float tile[32][33];
   __shared__ __attribute__((aligned(16))) float smean[32];
-  const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  const int j0 = bx * 32, i0 = by * 32;
   if (psum) {
     if (threadIdx.x < 32) {
       const int col = j0 + threadIdx.x;
@@ -609,7 +632,7 @@ __global__ __launch_bounds__(256) void center_x3_kernel(const float* __restrict_
       for (int k = 0; k < COL_CHUNKS; ++k) a += psum[(size_t)k * ld + col];
       a = a / (float)n;
       smean[threadIdx.x] = a;
-      if (mean_out && blockIdx.y == 0) mean_out[col] = a;
+      if (mean_out && by == 0) mean_out[col] = a;
     }
     __syncthreads();
   }
@@ -632,12 +655,18 @@ __global__ __launch_bounds__(256) void center_x3_kernel(const float* __restrict_
     x3_store4(Pt, ld, j0 + jl, i0 + 4 * ic, v);
   }
 }
+__global__ __launch_bounds__(256) void center_x3_kernel(const float* __restrict__ y, int n, int npad, int ld,
+                                                        const float* __restrict__ mean, __bf16* __restrict__ Pc,
+                                                        __bf16* __restrict__ Pt, const float* __restrict__ psum = nullptr,
+                                                        float* __restrict__ mean_out = nullptr) {
+  center_x3_kernel_body(y, n, npad, ld, mean, Pc, Pt, psum, mean_out, (int)blockIdx.x, (int)blockIdx.y);
+}
 // loss = sum(partial)/d^2 + sum_c |mx-my|/d ;  sgn[c] = sign(my - mx)
-__global__ __launch_bounds__(256) void moment_finalize_kernel(const float* __restrict__ partial, int count,
+__device__ __forceinline__ void moment_finalize_kernel_body(const float* __restrict__ partial, int count,
                                                               const float* __restrict__ mx,
                                                               const float* __restrict__ my, int d, int ld,
                                                               float* __restrict__ sgn,
-                                                              float* __restrict__ loss_out) {
+                                                              float* __restrict__ loss_out, const int bx, const int by) {
   __shared__ float red[4];
   float a = 0.f, b = 0.f;
   for (int i = threadIdx.x; i < count; i += 256) a += partial[i];
@@ -649,6 +678,13 @@ __global__ __launch_bounds__(256) void moment_finalize_kernel(const float* __res
   a = block_sum_256(a, red);
   b = block_sum_256(b, red);
   if (threadIdx.x == 0) loss_out[0] = a / ((float)d * (float)d) + b / (float)d;
+}
+__global__ __launch_bounds__(256) void moment_finalize_kernel(const float* __restrict__ partial, int count,
+                                                              const float* __restrict__ mx,
+                                                              const float* __restrict__ my, int d, int ld,
+                                                              float* __restrict__ sgn,
+                                                              float* __restrict__ loss_out) {
+  moment_finalize_kernel_body(partial, count, mx, my, d, ld, sgn, loss_out, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------- Sinkhorn-Knopp (build-defined, see strotss_hip.h)
@@ -755,6 +791,55 @@ __global__ __launch_bounds__(256) void sk_assemble_kernel(const float* __restric
   }
   const float tot = block_sum_256(qs, red);
   if (threadIdx.x == 0) q[j] = tot;
+}
+
+// ---- merged launches of strotss_step_losses_fwd_bwd (round 4): kernels that depend on the same inputs and on nothing else
+// share ONE launch, each keeping its own blocks and its own arithmetic (the `_body` functions above are the kernels' bodies).
+// Prologue: [A] reciprocal norms + x3 panels of the prediction and content rows, [B] column partial sums of the prediction
+// rows, [C] YUV rows of style and prediction (palette term), [D] the prediction rows transposed as x3 panels (B operand of
+// the self-similarity backward GEMM) -- all functions of the gathered rows alone.
+struct StepPrologueArgs {
+  const float* pred; const float* content; int n; int ld;
+  float* rp; __bf16* xp; float* rc; __bf16* xc;                 // A
+  float* psum;                                                  // B
+  const float* style; int ns; f32x4* ys; f32x4* yp; int rgb_to_yuv;   // C
+  int ldc; __bf16* xt;                                          // D
+  int nA, nB, nC;                                               // block counts of the first three ranges
+};
+__global__ __launch_bounds__(256) void step_losses_prologue_kernel(StepPrologueArgs a) {
+  int b = (int)blockIdx.x;
+  if (b < a.nA) {
+    const int half = a.nA / 2;
+    row_inv_norm_x3_kernel_body(a.pred, a.n, a.ld, a.rp, a.xp, a.content, a.n, a.rc, a.xc, b % half, b / half);
+    return;
+  }
+  b -= a.nA;
+  if (b < a.nB) {
+    const int gx = (a.ld + 63) / 64;
+    col_sum_partial_kernel_body(a.pred, a.n, a.ld, a.psum, b % gx, b / gx);
+    return;
+  }
+  b -= a.nB;
+  if (b < a.nC) {
+    const int half = a.nC / 2;
+    palette_prepare_kernel_body(a.style, a.ns, a.ld, a.ys, a.rgb_to_yuv, a.pred, a.n, a.yp, b % half, b / half);
+    return;
+  }
+  b -= a.nC;
+  const int gx = a.ld / 32;
+  center_x3_kernel_body(a.pred, a.n, a.ldc, a.ld, (const float*)nullptr, (__bf16*)nullptr, a.xt, (const float*)nullptr,
+                        (float*)nullptr, b % gx, b / gx);
+}
+// [self-similarity row statistics | moment-matching finalisation]: both wait for the grouped forward GEMMs only
+__global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __restrict__ Dx, const float* __restrict__ Dy, int n,
+                                                               int ldc, float sscale, float* __restrict__ isx,
+                                                               float* __restrict__ isy, float* __restrict__ tt,
+                                                               float* __restrict__ lossrow, const float* __restrict__ partial,
+                                                               int count, const float* __restrict__ mx,
+                                                               const float* __restrict__ my, int d, int ld,
+                                                               float* __restrict__ sgn, float* __restrict__ loss_moment) {
+  if ((int)blockIdx.x < n) selfsim_rowstat_kernel_body(Dx, Dy, n, ldc, sscale, isx, isy, tt, lossrow, (int)blockIdx.x, 0);
+  else moment_finalize_kernel_body(partial, count, mx, my, d, ld, sgn, loss_moment, 0, 0);
 }
 
 // The same assembly for dist_metrics 'l2' / 'both' (losses.py:18-28): M = l2 or cosine + l2; S holds the l2 part with the sign
@@ -1338,38 +1423,40 @@ int strotss_moment_fwd_bwd(const float* style_mean, const float* style_cov, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The three feature-space losses of one train step (run_strotss.py:131-142: self_similarity + moment_matching + relaxed_emd
-// on the same prediction rows) in ONE call whose three forward GEMMs share ONE launch (st_loss_forward_group_x3).  Every
+// The four loss terms of one train step (run_strotss.py:131-142: self_similarity + moment_matching + relaxed_emd + the YUV
+// palette relaxed_emd on the same prediction rows) in ONE call whose three forward GEMMs share ONE launch (st_loss_forward_group_x3).  Every
 // kernel, tile shape and summation order is that of the three separate entry points called in this order
-// (strotss_selfsim_fwd_bwd, strotss_moment_fwd_bwd, strotss_remd_cos_fwd_bwd_panels): bit for bit the same losses and
-// gradient rows; two launches and the idle slots of three underfilled GEMMs less.  bf16x3 core only (STROTSS_X3 / _COST /
+// (strotss_selfsim_fwd_bwd, strotss_moment_fwd_bwd, strotss_remd_cos_fwd_bwd_panels, strotss_palette_remd_fwd_bwd): bit for bit the
+// same losses and gradient rows; 13 launches instead of 21 (one prologue launch, one for row statistics + moment scalars).  bf16x3 core only (STROTSS_X3 / _COST /
 // _MOMENT = 0: STROTSS_EINVAL, the caller takes the separate entry points).
 size_t strotss_step_losses_workspace_bytes(int ns, int n, int ld) {
   Workspace w = Workspace::planner();
-  SelfsimWs a; MomentWs b; RemdWs c;
-  a.plan(w, n, ld); b.plan(w, n, ld); c.plan(w, ns, n, ld);
+  SelfsimWs a; MomentWs b; RemdWs c, p;
+  a.plan(w, n, ld); b.plan(w, n, ld); c.plan(w, ns, n, ld); p.plan(w, ns, n, 0);
   return w.off;
 }
 
 int strotss_step_losses_fwd_bwd(const float* pred, const float* content, int n, int d, int ld, const float* style,
                                 const float* style_inv_norm, const void* style_panels, int ns, const float* style_mean,
-                                const float* style_cov, float g_content, float g_moment, float g_remd, float* gpred,
-                                float* loss_content, float* loss_moment, float* loss_remd, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                const float* style_cov, float g_content, float g_moment, float g_remd, float g_palette,
+                                float* gpred, float* loss_content, float* loss_moment, float* loss_remd, float* loss_palette,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(pred && content && style && style_inv_norm && style_panels && style_mean && style_cov && gpred && loss_content &&
-               loss_moment && loss_remd && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
+               loss_moment && loss_remd && loss_palette && workspace && ns > 0 && feat_ok(n, d, ld), STROTSS_EINVAL);
   ST_CHECK_ARG(ld % 32 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(ns <= REMD_MAX_LIST, STROTSS_ERANGE);
   ST_CHECK_ARG(cost_x3() && moment_x3(), STROTSS_EINVAL);
   Workspace w(workspace, workspace_bytes);
-  SelfsimWs s; MomentWs m; RemdWs r;
-  ST_CHECK_ARG(s.plan(w, n, ld) && m.plan(w, n, ld) && r.plan(w, ns, n, ld), STROTSS_EINVAL);
+  SelfsimWs s; MomentWs m; RemdWs r, pl;
+  ST_CHECK_ARG(s.plan(w, n, ld) && m.plan(w, n, ld) && r.plan(w, ns, n, ld) && pl.plan(w, ns, n, 0), STROTSS_EINVAL);
   hipStream_t st = (hipStream_t)stream;
   const int ldc = s.ldc;
-  // ---- prologues: reciprocal norms + x3 panels of the prediction and content rows; column means, centred panels
-  hipLaunchKernelGGL(row_inv_norm_x3_kernel, dim3(cdiv(n, 4), 2), dim3(256), 0, st, pred, n, ld, s.rp, s.xp, content, n, s.rc,
-                     s.xc);
-  hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(ld, 64), COL_CHUNKS), dim3(256), 0, st, pred, n, ld, m.psum);
+  // ---- ONE prologue launch: norms + panels of prediction and content rows | column partial sums | YUV rows | transposed panels
+  StepPrologueArgs pa{pred, content, n, ld, s.rp, s.xp, s.rc, s.xc, m.psum, style, ns, pl.ys, pl.yp, 1, ldc, s.xt,
+                      2 * cdiv(n, 4), cdiv(ld, 64) * COL_CHUNKS, 2 * cdiv(n > ns ? n : ns, 256)};
+  hipLaunchKernelGGL(step_losses_prologue_kernel, dim3((unsigned)(pa.nA + pa.nB + pa.nC + (ld / 32) * (ldc / 32))), dim3(256), 0, st,
+                     pa);
+  // the centred rows (both ways round) need the column sums: their own launch
   hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, m.rows / 32), dim3(256), 0, st, pred, n, m.rows, ld,
                      (const float*)nullptr, m.Pc, m.Pt, (const float*)m.psum, m.mean);
   LAUNCH_OK();
@@ -1378,19 +1465,13 @@ int strotss_step_losses_fwd_bwd(const float* pred, const float* content, int n, 
   CHK(st_loss_forward_group_x3(m.Pt, m.rows, ld, style_cov, m.Tp, 1.0f / (float)n, m.partial, &n_partial,
                                s.xp, s.rp, n, s.xc - s.xp, s.rc - s.rp, s.Dx, ldc, s.Dy - s.Dx,
                                style_panels, style_inv_norm, ns, r.C, r.ldt, st));
-  // ---- self-similarity: statistics, symmetrised gradient matrix, backward GEMM
-  hipLaunchKernelGGL(selfsim_rowstat_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, n, ldc, 1.0f / (float)n, s.sx, s.sy,
-                     s.tt, s.lossrow);
+  // ---- self-similarity statistics | moment loss scalars + mean-gradient signs: one launch
+  hipLaunchKernelGGL(rowstat_finalize_kernel, dim3(n + 1), dim3(256), 0, st, s.Dx, s.Dy, n, ldc, 1.0f / (float)n, s.sx, s.sy,
+                     s.tt, s.lossrow, m.partial, n_partial, style_mean, m.mean, d, ld, m.sgn, loss_moment);
   hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, s.tt, s.rp, n, ldc, ldc,
                      1.0f / (float)n, s.Mq, s.qdot, s.mp, s.lossrow, 1.0f / (float)n, loss_content);
-  hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, ldc / 32), dim3(256), 0, st, pred, n, ldc, ld, (const float*)nullptr,
-                     (__bf16*)nullptr, s.xt);
   LAUNCH_OK();
   CHK(st_selfsim_bwd_x3(s.mp, ldc, s.xt, pred, s.rp, s.qdot, n, ld, g_content, gpred, st));
-  // ---- moment matching: loss scalars + mean-gradient signs, backward GEMM
-  hipLaunchKernelGGL(moment_finalize_kernel, dim3(1), dim3(256), 0, st, m.partial, n_partial, style_mean, m.mean, d, ld,
-                     m.sgn, loss_moment);
-  LAUNCH_OK();
   CHK(st_moment_bwd_x3(m.Pc, n, ld, m.Tp, g_moment * 2.0f / ((float)n * (float)d * (float)d), m.sgn,
                        g_moment / ((float)d * (float)n), gpred, st));
   // ---- relaxed EMD on the cost matrix the grouped launch left in r.C: minima, branch, sparse backward
@@ -1401,6 +1482,13 @@ int strotss_step_losses_fwd_bwd(const float* pred, const float* content, int n, 
                      r.cmin, n, 1, loss_remd, r.sel, 0);
   hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, r.C, ldt, style, style_inv_norm, ns, pred, s.rp, n,
                      ld, r.rmin, r.rcnt, r.cmin, r.ccnt, r.sel, g_remd, gpred);
+  // ---- palette term (run_strotss.py:37-39) on the YUV rows the prologue made: minima, branch, backward
+  hipLaunchKernelGGL(palette_minima_kernel, dim3(ns + n), dim3(256), 0, st, pl.ys, ns, pl.yp, n, pl.rmin, pl.rcnt, pl.cmin,
+                     pl.ccnt);
+  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, (const float*)nullptr, (const float*)nullptr,
+                     n, 0, pl.cmin, pl.ccnt, pl.rmin, ns, 0, loss_palette, pl.sel, 0);
+  hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, pl.ys, ns, pl.yp, n, pl.rmin, pl.rcnt, pl.cmin, pl.ccnt,
+                     pl.sel, g_palette, gpred, ld, 1);
   ST_LAUNCH_RET();
 }
 

@@ -114,7 +114,7 @@ SIGNATURES = {
     "strotss_remd_metric_workspace_bytes": (_Z, [_I, _I]),
     "strotss_remd_metric_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _Z, _P]),
     "strotss_step_losses_workspace_bytes": (_Z, [_I, _I, _I]),
-    "strotss_step_losses_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    "strotss_step_losses_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "strotss_moment_workspace_bytes": (_Z, [_I, _I]),
     "strotss_moment_stats": (_I, [_P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "strotss_moment_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),

@@ -552,17 +552,18 @@ def step_losses_available() -> bool:
 
 
 def step_losses_fwd_bwd(pred, content, n, d, style, rs, style_panels, ns, style_mean, style_cov, g_content, g_moment, g_remd,
-                        gpred, loss_content, loss_moment, loss_remd):
-    """self_similarity + moment_matching + relaxed_emd (cosine) of one train step in ONE call, their three forward GEMMs in
-    ONE launch (strotss_step_losses_fwd_bwd): bit for bit selfsim_fwd_bwd, moment_fwd_bwd, remd_cos_fwd_bwd_after_selfsim."""
+                        g_palette, gpred, loss_content, loss_moment, loss_remd, loss_palette):
+    """self_similarity + moment_matching + relaxed_emd (cosine) + the YUV palette relaxed_emd of one train step in ONE call
+    (strotss_step_losses_fwd_bwd): one prologue launch, the three forward GEMMs in one launch, 13 launches in all; bit for
+    bit selfsim_fwd_bwd, moment_fwd_bwd, remd_cos_fwd_bwd_after_selfsim, palette_remd_fwd_bwd in this order."""
     l = _hip.lib()
     ld = int(pred.shape[1])
     nb = l.strotss_step_losses_workspace_bytes(ns, n, ld)
     ws = workspaces.get("step_losses", nb, pred.device)
     check(l.strotss_step_losses_fwd_bwd(ptr(pred), ptr(content), n, d, ld, ptr(style), ptr(rs), ptr(style_panels), ns,
                                         ptr(style_mean), ptr(style_cov), float(g_content), float(g_moment), float(g_remd),
-                                        ptr(gpred), ptr(loss_content), ptr(loss_moment), ptr(loss_remd), ptr(ws), nb,
-                                        stream_ptr()), "step_losses_fwd_bwd")
+                                        float(g_palette), ptr(gpred), ptr(loss_content), ptr(loss_moment), ptr(loss_remd),
+                                        ptr(loss_palette), ptr(ws), nb, stream_ptr()), "step_losses_fwd_bwd")
 
 
 def sinkhorn_cos_fwd_bwd(style, rs, ns, pred, n, d, l, n_iter, gscale, gpred, loss_out):

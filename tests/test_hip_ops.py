@@ -662,9 +662,10 @@ def test_remd_with_borrowed_panels_equals_the_plain_call_bitwise(ops, n, ns, d):
 
 @pytest.mark.parametrize("n,ns,d", [(64, 64, 67), (1024, 1024, 2179), (200, 333, 131), (1000, 700, 515)])
 def test_step_losses_one_call_equals_the_three_calls_bitwise(ops, n, ns, d):
-    """strotss_step_losses_fwd_bwd (self-similarity + moment matching + cosine relaxed EMD of a train step in one call, their
-    three forward GEMMs -- 2 x 136 symmetric cost tiles, 171 covariance tiles, 256 cost tiles at n = 1024 -- in ONE grouped
-    launch) == the three separate entry points in the engine's order: the three scalars and every gradient row, bit for bit."""
+    """strotss_step_losses_fwd_bwd (self-similarity + moment matching + cosine relaxed EMD + YUV palette term of a train step in
+    one call: one prologue launch for all four, the three forward GEMMs -- 2 x 136 symmetric cost tiles, 171 covariance tiles,
+    256 cost tiles at n = 1024 -- in ONE grouped launch, row statistics + moment scalars in one) == the four separate entry
+    points in the engine's order: the four scalars and every gradient row, bit for bit."""
     if not ops.step_losses_available():
         pytest.skip("bf16x3 core switched off")
     x = _feat(ns, d, 31); y = _feat(n, d, 32); c = _feat(n, d, 33)
@@ -675,17 +676,18 @@ def test_step_losses_one_call_equals_the_three_calls_bitwise(ops, n, ns, d):
     for grouped in (False, True, False, True):
         g = torch.zeros_like(by); l = torch.zeros(4, device="cuda")
         if grouped:
-            ops.step_losses_fwd_bwd(by, bc, n, d, bx, rs, panels, ns, mean, cov, 0.7, 0.3, 0.9, g, l[0:], l[1:], l[2:])
+            ops.step_losses_fwd_bwd(by, bc, n, d, bx, rs, panels, ns, mean, cov, 0.7, 0.3, 0.9, 0.4, g, l[0:], l[1:], l[2:], l[3:])
         else:
             ops.selfsim_fwd_bwd(by, bc, n, d, 0.7, g, l[0:])
             ops.moment_fwd_bwd(mean, cov, by, n, d, 0.3, g, l[1:])
             ops.remd_cos_fwd_bwd_after_selfsim(bx, rs, panels, ns, by, n, d, 0.9, g, l[2:])
+            ops.palette_remd_fwd_bwd(bx, ns, by, n, 0.4, g, l[3:])
         torch.cuda.synchronize()
         outs.append((g, l))
     for g, l in outs[1:]:
         assert torch.equal(l, outs[0][1]), (l, outs[0][1])
         assert torch.equal(g, outs[0][0])
-    assert all(float(v) != 0.0 for v in outs[0][1][:3])
+    assert all(float(v) != 0.0 for v in outs[0][1][:4])
     # against the float64 restatement (the separate calls have their own tests; this pins the grouped call's wiring)
     ref_c, _ = R.self_similarity_fwd_bwd(y, c)
     ref_m, _ = R.moment_matching_fwd_bwd(x, y)

@@ -124,9 +124,9 @@ def test_device_index_draw_equals_the_oracle_draw_element_for_element(h, w):
     dev_masks = [None if k is None else torch.from_numpy(keep[k].astype(np.uint8)).cuda() for k in regions]
     most, least = _ops.index_draw_counts(h, w, [None if k is None else keep[k] for k in regions])
     assert most <= 32768 and 0 <= least <= most       # (regions with fewer candidates than samples return fewer coordinates)
-    for n, seed, t0 in ((1024, 0, 0), (256, 0x1234567890, 41)):
+    for n, seed, t0 in ((1024, 0, 0), (256, 0x1234567890, 41), (1, 7, 3), (1000, 2 ** 63 + 5, 2 ** 32 - 2)):   # (the last: the counter wraps)
         R = len(regions)
-        counters = torch.tensor([t0 + r for r in range(R)], dtype=torch.int32, device="cuda")
+        counters = torch.tensor([t0 + r for r in range(R)], dtype=torch.int64).to(torch.int32).cuda()     # 32-bit draw numbers
         n_out = torch.full((R,), -1, dtype=torch.int32, device="cuda")
         out = [torch.full((n, 2), -7.0, device="cuda") for _ in range(R)]
         twin = RAND.PhiloxStream(seed, t0)
@@ -135,7 +135,7 @@ def test_device_index_draw_equals_the_oracle_draw_element_for_element(h, w):
             # key distribution -- instead of the fast one: both must give the oracle's coordinates)
             _ops.index_draw(h, w, n, seed, counters, out, dev_masks, n_out, general_path=(step == 1))
             torch.cuda.synchronize()
-            assert counters.tolist() == [t0 + (step + 1) * R + r for r in range(R)]
+            assert [c & 0xFFFFFFFF for c in counters.tolist()] == [(t0 + (step + 1) * R + r) & 0xFFFFFFFF for r in range(R)]
             for r, k in enumerate(regions):
                 assert twin.t == t0 + step * R + r
                 ref = O.make_indices(h, w, True, n, twin, mask=None if k is None else masks[k])

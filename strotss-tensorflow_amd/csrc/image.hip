@@ -348,27 +348,41 @@ __device__ __forceinline__ SampleTap sample_tap(const strotss_maps_t& m, int k, 
   return t;
 }
 
-// one block per sample row
+// one block per sample row.  The row's 64-channel chunks (35 of them for the ten maps of a step) are dealt round-robin to the
+// block's four waves: every map is a random pixel of a large tensor (an HBM round trip), and ten of them walked one after the
+// other by the whole block made the kernel a chain of ten latencies (18 us for 2048 blocks, all resident at once).  Each wave
+// now walks its own quarter of the chunks -- the same loads, weights and arithmetic per element, bit for bit.
 __device__ __forceinline__ void gather_row(const strotss_maps_t& m, const float* __restrict__ idx, int s, int bilinear,
                                            float* __restrict__ out, int ld, int dtotal) {
   if (m.sample_range && (s < m.sample_range[0] || s >= m.sample_range[1])) return;      // not this rank's sample
   const float gx = idx[2 * s], gy = idx[2 * s + 1];
   float* o = out + (size_t)s * ld;
-  int off = 0;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int off = 0, chunk = 0;
   for (int k = 0; k < m.n_maps; ++k) {
-    const SampleTap t = sample_tap(m, k, gx, gy, bilinear);
-    const int c = m.c[k];
-    const float* src = m.map[k];
-    if (bilinear) {
-      const float* pa = src + (size_t)t.ia * c; const float* pb = src + (size_t)t.ib * c;
-      const float* pc = src + (size_t)t.ic * c; const float* pd = src + (size_t)t.id * c;
-      for (int ch = threadIdx.x; ch < c; ch += 256)
-        o[off + ch] = pa[ch] * t.wa + pb[ch] * t.wb + pc[ch] * t.wc + pd[ch] * t.wd;
-    } else {
-      const float* pa = src + (size_t)t.ia * c;
-      for (int ch = threadIdx.x; ch < c; ch += 256) o[off + ch] = pa[ch];
+    const int c = m.c[k], nchunk = (c + 63) >> 6;
+    // first chunk of this map that belongs to this wave: chunk ids chunk .. chunk + nchunk - 1, wave takes id % 4 == wave
+    int q0 = (wave - chunk) & 3;
+    if (q0 < nchunk) {
+      const SampleTap t = sample_tap(m, k, gx, gy, bilinear);
+      const float* src = m.map[k];
+      if (bilinear) {
+        const float* pa = src + (size_t)t.ia * c; const float* pb = src + (size_t)t.ib * c;
+        const float* pc = src + (size_t)t.ic * c; const float* pd = src + (size_t)t.id * c;
+        for (int q = q0; q < nchunk; q += 4) {
+          const int ch = q * 64 + lane;
+          if (ch < c) o[off + ch] = pa[ch] * t.wa + pb[ch] * t.wb + pc[ch] * t.wc + pd[ch] * t.wd;
+        }
+      } else {
+        const float* pa = src + (size_t)t.ia * c;
+        for (int q = q0; q < nchunk; q += 4) {
+          const int ch = q * 64 + lane;
+          if (ch < c) o[off + ch] = pa[ch];
+        }
+      }
     }
     off += c;
+    chunk += nchunk;
   }
   for (int ch = dtotal + threadIdx.x; ch < ld; ch += 256) o[ch] = 0.f;
 }
@@ -404,10 +418,15 @@ __global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m,
   if (m.sample_range && (s < m.sample_range[0] || s >= m.sample_range[1])) return;
   const float gx = idx[2 * s], gy = idx[2 * s + 1];
   const float* g = gfeat + (size_t)s * ld;
-  int off = 0;
+  // 64-channel chunks dealt round-robin to the four waves, as in the gather: a wave's chain of dependent latencies (tap
+  // arithmetic, gradient load, ReLU-mask load, atomic) covers a quarter of the maps instead of all of them
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int off = 0, chunk = 0;
   for (int k = 0; k < map_end; ++k) {
-    const int c = m.c[k];
-    if (k < map_begin) { off += c; continue; }
+    const int c = m.c[k], nchunk = (c + 63) >> 6;
+    const int q0 = (wave - chunk) & 3;
+    chunk += nchunk;
+    if (k < map_begin || q0 >= nchunk) { off += c; continue; }
     const SampleTap t = sample_tap(m, k, gx, gy, 1);
     const float* act = m.map[k];
     float* dst = m.gmap[k];
@@ -416,19 +435,19 @@ __global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m,
     const float ww[4] = {t.wa, t.wb, t.wc, t.wd};
     // Wave-uniform trip count and a per-lane `in` test made afresh in every trip: no exec mask or tap predicate is kept in
     // an SGPR pair across the channel loop (every saved mask below lives for the few instructions around one atomic).
-    for (int base = 0; base < c; base += 256) {
-      const int ch = base + (int)threadIdx.x;
+    for (int q = q0; q < nchunk; q += 4) {
+      const int ch = q * 64 + lane;
       const bool in = ch < c;
       const int chc = in ? ch : c - 1;                                     // clamped: the load below is always in range
       const float gv = in ? g[off + chc] : 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int tq = 0; tq < 4; ++tq) {
         // The skip is decided per lane and per trip from the PRODUCT (a vector compare on a value made in this
         // iteration), never from a wave-uniform `ww[q] == 0` test: the compiler kept that one as four lane masks in
         // s[2:9] across the whole channel loop, and the build that lost whole (wave, tap) contributions next to another
         // process was the one with tap 0's mask in s[2:3].  A zero product adds nothing.
-        const float v = ww[q] * gv;
-        const size_t o = (size_t)ii[q] * c + chc;
+        const float v = ww[tq] * gv;
+        const size_t o = (size_t)ii[tq] * c + chc;
         if (v != 0.f && (!masked || act[o] > 0.f)) atomicAdd(&dst[o], v);
       }
     }

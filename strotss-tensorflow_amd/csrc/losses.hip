@@ -369,8 +369,18 @@ __global__ __launch_bounds__(256) void remd_cos_bwd_kernel(
   const float* y = pred + (size_t)j * ld;
   float* gy = gpred + (size_t)j * ld;
   for (int k = t; k < ld; k += 256) {
+    // the list's rows are summed in list order (bitwise reproducible), eight loads in flight at a time: a prediction row that
+    // many style rows point at (row branch) walked its list as one chain of dependent L2 round trips
     float acc = 0.f;
-    for (int e = 0; e < total; ++e) acc += lw[e] * style[(size_t)li[e] * ld + k];
+    int e = 0;
+    for (; e + 8 <= total; e += 8) {
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = style[(size_t)li[e + u] * ld + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += lw[e + u] * v8[u];
+    }
+    for (; e < total; ++e) acc += lw[e] * style[(size_t)li[e] * ld + k];
     gy[k] += gscale * rj * (-acc - y[k] * rj * q * live);
   }
 }

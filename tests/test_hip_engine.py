@@ -560,7 +560,10 @@ def test_run_schedule_matches_oracle_run_scales(tmp_path, start_level):
         for k, ref in zip(("loss", "loss_c", "loss_s"), first[2:]):
             assert abs(t["steps"][0][k] - ref) < 5e-5 * max(1.0, abs(ref)), (t["i"], k, t["steps"][0][k], ref)
         second = [s_ for s_ in osteps if s_[0] == t["i"] and s_[1] == 1][0]
-        assert abs(t["steps"][1]["loss"] - second[2]) < 1e-2 * abs(second[2])
+        # (free-running second step: a whole RMSprop quantum 10*lr wherever a near-zero gradient entry changed sign between f32
+        # and f64 -- and the float atomics of the tap adjoint reorder last bits from run to run: 1 % was seen to fail once in
+        # ~15 runs with the fused kernel forced; the 200-step trajectory test states the free-running tolerance)
+        assert abs(t["steps"][1]["loss"] - second[2]) < 2e-2 * abs(second[2]), (t["i"], t["steps"][1]["loss"], second[2])
         # fresh RMSprop slots per scale: after 2 steps no pixel moved by more than 2 first-step quanta per level
         assert float((t["final"] - t["init"]).abs().max()) <= 6 * 2 * 10 * t["lr"] * 1.05
     assert [t["lr"] for t in tr][-1] == 1e-3 and all(t["lr"] == 2e-3 for t in tr[:-1])

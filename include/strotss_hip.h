@@ -386,7 +386,9 @@ int strotss_remd_metric_fwd_bwd(const float* style, int ns, const float* pred, i
  * gpred += g_content * d(content)/d(pred) + g_moment * ... + g_remd * ... + g_palette * ....  Bit for bit
  * strotss_selfsim_fwd_bwd, strotss_moment_fwd_bwd, strotss_remd_cos_fwd_bwd_panels and strotss_palette_remd_fwd_bwd called in
  * this order; the three forward GEMMs (two symmetric cost matrices, covariance, prediction x style cost matrix) share ONE
- * launch, the prologues of all four terms another, row statistics and moment scalars a third: 13 launches instead of 21.
+ * launch, the prologues of all four terms another, every statistic of the forward products (self-similarity rows, moment
+ * scalars, REMD and palette minima) a third, the two branch selections + the self-similarity gradient matrix a fourth:
+ * 9 launches instead of 21.
  * bf16x3 core only: STROTSS_EINVAL when STROTSS_X3 / _COST / _MOMENT switch it off (take the separate entry points). */
 size_t strotss_step_losses_workspace_bytes(int ns, int n, int ld);
 int strotss_step_losses_fwd_bwd(const float* pred, const float* content, int n, int d, int ld, const float* style,

@@ -146,19 +146,37 @@ __global__ __launch_bounds__(256) void selfsim_rowstat_kernel(const float* __res
 // rows i of Dx and Dy, no N x N intermediate.  Mq[i,j] = M[i,j] * r[j] (zero for n <= j < kpad);
 // qdot[i] = sum_j M[i,j] (1 - Dx[i,j])   (= xhat_i . dL/dxhat_i).  Workgroup 0 also reduces the rows' losses:
 // loss_out[0] = loss_scale * sum_j lossrow[j] (fixed order).
-__global__ __launch_bounds__(256) void selfsim_sym_kernel(const float* __restrict__ Dx, const float* __restrict__ Dy,
-                                                          const float* __restrict__ isx, const float* __restrict__ isy,
-                                                          const float* __restrict__ tt, const float* __restrict__ r,
-                                                          int n, int ldc, int kpad, float sscale,
-                                                          float* __restrict__ Mq, float* __restrict__ qdot,
-                                                          __bf16* __restrict__ Mp, const float* __restrict__ lossrow,
-                                                          float loss_scale, float* __restrict__ loss_out) {
+// group_sum_256: block_sum_256's arithmetic for a GROUP of 256 threads (tid = index in the group, red = the group's four
+// floats of LDS) -- the whole workgroup of the stand-alone kernel, or one quarter of a 1024-thread workgroup of
+// select_sym_kernel; every thread of the workgroup reaches its barriers.
+__device__ __forceinline__ float group_sum_256(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+struct SelfsimSymArgs {
+  const float *Dx, *Dy, *isx, *isy, *tt, *r;
+  int n, ldc, kpad; float sscale;
+  float *Mq, *qdot; __bf16* Mp; const float* lossrow; float loss_scale; float* loss_out;
+};
+// row i by the 256 threads of one group; i >= n: no loads or stores, barriers only.  with_loss (uniform over the WORKGROUP):
+// every group also reduces the rows' losses the same way, group i == 0 writes it.
+__device__ __forceinline__ void selfsim_sym_body(const SelfsimSymArgs& a, const int i, const int tid, float* red,
+                                                 const bool with_loss) {
+  const float* __restrict__ Dx = a.Dx; const float* __restrict__ Dy = a.Dy;
+  const float* __restrict__ isx = a.isx; const float* __restrict__ isy = a.isy;
+  const float* __restrict__ tt = a.tt; const float* __restrict__ r = a.r;
+  float* __restrict__ Mq = a.Mq; __bf16* __restrict__ Mp = a.Mp;
+  const int n = a.n, ldc = a.ldc, kpad = a.kpad;
+  const float sscale = a.sscale;
   // Mp != NULL: Mq goes out as x3 panels (rows = n, K = kpad; mfma_x3.h) for the bf16x3 backward GEMM instead
-  __shared__ float red[4];
-  const int i = blockIdx.x;
-  const float isx_i = isx[i], isy_i = isy[i], t_i = tt[i];
+  const bool live = i < n;
+  const int ic = live ? i : 0;
+  const float isx_i = isx[ic], isy_i = isy[ic], t_i = tt[ic];
   float acc = 0.f;
-  for (int j = threadIdx.x; j < kpad; j += 256) {
+  for (int j = tid; live && j < kpad; j += 256) {
     float out = 0.f;
     if (j < n) {
       const float dx = Dx[(size_t)i * ldc + j], dy = Dy[(size_t)i * ldc + j];
@@ -179,14 +197,18 @@ __global__ __launch_bounds__(256) void selfsim_sym_kernel(const float* __restric
       Mq[(size_t)i * ldc + j] = out;
     }
   }
-  acc = block_sum_256(acc, red);
-  if (threadIdx.x == 0) qdot[i] = acc;
-  if (i == 0) {
-    float a = 0.f;
-    for (int j = threadIdx.x; j < n; j += 256) a += lossrow[j];
-    a = block_sum_256(a, red);
-    if (threadIdx.x == 0) loss_out[0] = a * loss_scale;
+  acc = group_sum_256(acc, red, tid);
+  if (tid == 0 && live) a.qdot[i] = acc;
+  if (with_loss) {
+    float l = 0.f;
+    for (int j = tid; j < n; j += 256) l += a.lossrow[j];
+    l = group_sum_256(l, red, tid);
+    if (tid == 0 && i == 0) a.loss_out[0] = l * a.loss_scale;
   }
+}
+__global__ __launch_bounds__(256) void selfsim_sym_kernel(SelfsimSymArgs a) {
+  __shared__ float red[4];
+  selfsim_sym_body(a, (int)blockIdx.x, (int)threadIdx.x, red, blockIdx.x == 0);
 }
 
 // out[0] = scale * sum(partial[0..count))      (single block, fixed order)
@@ -244,16 +266,20 @@ __device__ __forceinline__ void col_min_partial_block(const float* __restrict__ 
 }
 // Row minima (one workgroup per row: rows x n matrix) and stage 1 of the column minima in ONE launch:
 // workgroups [0, rows) take the rows, the following cdiv(n, 64) * COL_CHUNKS the column chunks.
-__global__ __launch_bounds__(256) void row_col_min_kernel(const float* __restrict__ C, int rows, int n, int ldc,
-                                                          float* __restrict__ rmin, float* __restrict__ rcnt,
-                                                          float* __restrict__ pmin, float* __restrict__ pcnt) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ void row_col_min_kernel_body(const float* __restrict__ C, int rows, int n, int ldc,
+                                                        float* __restrict__ rmin, float* __restrict__ rcnt,
+                                                        float* __restrict__ pmin, float* __restrict__ pcnt, const int b) {
   if (b < rows) {
     row_min_block(C, b, n, ldc, rmin, rcnt);
   } else {
     const int gx = (n + 63) / 64, bb = b - rows;
     col_min_partial_block(C, bb % gx, bb / gx, rows, n, ldc, pmin, pcnt);
   }
+}
+__global__ __launch_bounds__(256) void row_col_min_kernel(const float* __restrict__ C, int rows, int n, int ldc,
+                                                          float* __restrict__ rmin, float* __restrict__ rcnt,
+                                                          float* __restrict__ pmin, float* __restrict__ pcnt) {
+  row_col_min_kernel_body(C, rows, n, ldc, rmin, rcnt, pmin, pcnt, (int)blockIdx.x);
 }
 // Stage 2 of the column minima + the choice of the REMD branch, one workgroup of 1024 threads (a column per thread:
 // its 2 x COL_CHUNKS partials are all in flight at once):
@@ -272,13 +298,12 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {     // fi
   for (int k = 0; k < 16; ++k) a += red[k];
   return a;
 }
-__global__ __launch_bounds__(1024) void col_min_final_select_kernel(const float* __restrict__ pmin,
-                                                                    const float* __restrict__ pcnt, int n, int ldc,
-                                                                    float* __restrict__ cmin, float* __restrict__ ccnt,
-                                                                    const float* __restrict__ rowmin, int rows,
-                                                                    int col_is_x, float* __restrict__ loss_out,
-                                                                    int* __restrict__ sel, int swapped) {
-  __shared__ float red[16];
+__device__ __forceinline__ void col_min_final_select_kernel_body(const float* __restrict__ pmin,
+                                                                  const float* __restrict__ pcnt, int n, int ldc,
+                                                                  float* __restrict__ cmin, float* __restrict__ ccnt,
+                                                                  const float* __restrict__ rowmin, int rows,
+                                                                  int col_is_x, float* __restrict__ loss_out,
+                                                                  int* __restrict__ sel, int swapped, float* red) {
   float a = 0.f, b = 0.f;
   for (int j = threadIdx.x; j < n; j += 1024) {
     if (pmin) {
@@ -310,6 +335,15 @@ __global__ __launch_bounds__(1024) void col_min_final_select_kernel(const float*
     loss_out[0] = s ? rx : ry;
     sel[0] = s;
   }
+}
+__global__ __launch_bounds__(1024) void col_min_final_select_kernel(const float* __restrict__ pmin,
+                                                                    const float* __restrict__ pcnt, int n, int ldc,
+                                                                    float* __restrict__ cmin, float* __restrict__ ccnt,
+                                                                    const float* __restrict__ rowmin, int rows,
+                                                                    int col_is_x, float* __restrict__ loss_out,
+                                                                    int* __restrict__ sel, int swapped) {
+  __shared__ float red[16];
+  col_min_final_select_kernel_body(pmin, pcnt, n, ldc, cmin, ccnt, rowmin, rows, col_is_x, loss_out, sel, swapped, red);
 }
 
 #define REMD_MAX_LIST 2048
@@ -368,20 +402,66 @@ __global__ __launch_bounds__(256) void remd_cos_bwd_kernel(
   const float live = (rj < 1.0f / sqrtf(1e-12f)) ? 1.f : 0.f;
   const float* y = pred + (size_t)j * ld;
   float* gy = gpred + (size_t)j * ld;
-  for (int k = t; k < ld; k += 256) {
-    // the list's rows are summed in list order (bitwise reproducible), eight loads in flight at a time: a prediction row that
-    // many style rows point at (row branch) walked its list as one chain of dependent L2 round trips
-    float acc = 0.f;
+  // The list's rows are summed in list order per channel (bitwise reproducible).  A prediction row that many style rows point
+  // at (row branch) used to walk its list once per 256-channel slice, eight 4-byte loads in flight: ~9 x L/8 dependent L2
+  // round trips.  Now a thread owns up to three float4 columns (k4, k4 + 256, k4 + 512 of the ld / 4 <= 768) and walks the
+  // list ONCE with 8 entries x 3 sixteen-byte loads in flight: L/8 round trips, the same additions in the same order.
+  const int nv = ld >> 2;
+  const f32x4* __restrict__ S4 = (const f32x4*)style;
+  const f32x4* __restrict__ y4 = (const f32x4*)y;
+  f32x4* __restrict__ gy4 = (f32x4*)gy;
+  for (int k0 = t; k0 < nv; k0 += 768) {
+    const int k1 = min(k0 + 256, nv - 1), k2 = min(k0 + 512, nv - 1);      // clamped: loaded unconditionally, stored if in range
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
     int e = 0;
     for (; e + 8 <= total; e += 8) {
-      float v8[8];
+      f32x4 v0[8], v1[8], v2[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v8[u] = style[(size_t)li[e + u] * ld + k];
+      for (int u = 0; u < 8; ++u) {
+        const f32x4* row = S4 + (size_t)li[e + u] * nv;
+        v0[u] = row[k0]; v1[u] = row[k1]; v2[u] = row[k2];
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += lw[e + u] * v8[u];
+      for (int u = 0; u < 8; ++u) {
+        const float w = lw[e + u];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          a0[c4] = __builtin_fmaf(w, v0[u][c4], a0[c4]);
+          a1[c4] = __builtin_fmaf(w, v1[u][c4], a1[c4]);
+          a2[c4] = __builtin_fmaf(w, v2[u][c4], a2[c4]);
+        }
+      }
     }
-    for (; e < total; ++e) acc += lw[e] * style[(size_t)li[e] * ld + k];
-    gy[k] += gscale * rj * (-acc - y[k] * rj * q * live);
+    for (; e < total; ++e) {
+      const f32x4* row = S4 + (size_t)li[e] * nv;
+      const f32x4 u0 = row[k0], u1 = row[k1], u2 = row[k2];
+      const float w = lw[e];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        a0[c4] = __builtin_fmaf(w, u0[c4], a0[c4]);
+        a1[c4] = __builtin_fmaf(w, u1[c4], a1[c4]);
+        a2[c4] = __builtin_fmaf(w, u2[c4], a2[c4]);
+      }
+    }
+    const float s = gscale * rj;
+    {
+      f32x4 g = gy4[k0]; const f32x4 yy = y4[k0];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) g[c4] += s * (-a0[c4] - yy[c4] * rj * q * live);
+      gy4[k0] = g;
+    }
+    if (k0 + 256 < nv) {
+      f32x4 g = gy4[k1]; const f32x4 yy = y4[k1];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) g[c4] += s * (-a1[c4] - yy[c4] * rj * q * live);
+      gy4[k1] = g;
+    }
+    if (k0 + 512 < nv) {
+      f32x4 g = gy4[k2]; const f32x4 yy = y4[k2];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) g[c4] += s * (-a2[c4] - yy[c4] * rj * q * live);
+      gy4[k2] = g;
+    }
   }
 }
 
@@ -500,12 +580,11 @@ __device__ __forceinline__ float palette_cost(const f32x4 x, const f32x4 y, floa
 }
 // Minima and their multiplicities, rows and columns in ONE launch: workgroup b < ns takes style row b (minimum over
 // the predictions j), workgroup ns + j the prediction j (minimum over the style rows i).
-__global__ __launch_bounds__(256) void palette_minima_kernel(const f32x4* __restrict__ ys, int ns,
-                                                             const f32x4* __restrict__ yp, int n,
-                                                             float* __restrict__ rmin, float* __restrict__ rcnt,
-                                                             float* __restrict__ cmin, float* __restrict__ ccnt) {
+__device__ __forceinline__ void palette_minima_kernel_body(const f32x4* __restrict__ ys, int ns,
+                                                           const f32x4* __restrict__ yp, int n,
+                                                           float* __restrict__ rmin, float* __restrict__ rcnt,
+                                                           float* __restrict__ cmin, float* __restrict__ ccnt, const int b) {
   __shared__ float red[4];
-  const int b = blockIdx.x;
   const bool row = b < ns;
   const f32x4 mine = row ? ys[b] : yp[b - ns];
   const f32x4* other = row ? yp : ys;
@@ -527,6 +606,12 @@ __global__ __launch_bounds__(256) void palette_minima_kernel(const f32x4* __rest
   if (threadIdx.x == 0) {
     if (row) { rmin[b] = mn; rcnt[b] = c; } else { cmin[b - ns] = mn; ccnt[b - ns] = c; }
   }
+}
+__global__ __launch_bounds__(256) void palette_minima_kernel(const f32x4* __restrict__ ys, int ns,
+                                                             const f32x4* __restrict__ yp, int n,
+                                                             float* __restrict__ rmin, float* __restrict__ rcnt,
+                                                             float* __restrict__ cmin, float* __restrict__ ccnt) {
+  palette_minima_kernel_body(ys, ns, yp, n, rmin, rcnt, cmin, ccnt, (int)blockIdx.x);
 }
 // One wave per pred sample j.
 __global__ __launch_bounds__(64) void palette_bwd_kernel(
@@ -840,16 +925,42 @@ __global__ __launch_bounds__(256) void step_losses_prologue_kernel(StepPrologueA
   center_x3_kernel_body(a.pred, a.n, a.ldc, a.ld, (const float*)nullptr, (__bf16*)nullptr, a.xt, (const float*)nullptr,
                         (float*)nullptr, b % gx, b / gx);
 }
-// [self-similarity row statistics | moment-matching finalisation]: both wait for the grouped forward GEMMs only
-__global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __restrict__ Dx, const float* __restrict__ Dy, int n,
-                                                               int ldc, float sscale, float* __restrict__ isx,
-                                                               float* __restrict__ isy, float* __restrict__ tt,
-                                                               float* __restrict__ lossrow, const float* __restrict__ partial,
-                                                               int count, const float* __restrict__ mx,
-                                                               const float* __restrict__ my, int d, int ld,
-                                                               float* __restrict__ sgn, float* __restrict__ loss_moment) {
-  if ((int)blockIdx.x < n) selfsim_rowstat_kernel_body(Dx, Dy, n, ldc, sscale, isx, isy, tt, lossrow, (int)blockIdx.x, 0);
-  else moment_finalize_kernel_body(partial, count, mx, my, d, ld, sgn, loss_moment, 0, 0);
+// After the grouped forward GEMMs, everything that reads their results (or the prologue's) and nothing else, in ONE launch:
+// [self-similarity row statistics (n blocks) | moment-matching finalisation (1) | REMD row minima + stage 1 of the column
+// minima (n + cdiv(ns, 64) * COL_CHUNKS) | palette minima (ns + n)].  Every range keeps its own blocks and arithmetic.
+struct StepStatsArgs {
+  const float *Dx, *Dy; int n, ldc; float sscale; float *isx, *isy, *tt, *lossrow;                 // self-similarity rows
+  const float* partial; int count; const float *mx, *my; int d, ld; float *sgn, *loss_moment;       // moment finalisation
+  const float* C; int ns, ldt; float *rmin, *rcnt, *pmin, *pcnt;                                   // REMD minima
+  const f32x4 *ys, *yp; float *prmin, *prcnt, *pcmin, *pccnt;                                      // palette minima
+};
+__global__ __launch_bounds__(256) void step_losses_stats_kernel(StepStatsArgs a) {
+  int b = (int)blockIdx.x;
+  if (b < a.n) { selfsim_rowstat_kernel_body(a.Dx, a.Dy, a.n, a.ldc, a.sscale, a.isx, a.isy, a.tt, a.lossrow, b, 0); return; }
+  b -= a.n;
+  if (b == 0) { moment_finalize_kernel_body(a.partial, a.count, a.mx, a.my, a.d, a.ld, a.sgn, a.loss_moment, 0, 0); return; }
+  b -= 1;
+  const int nmin = a.n + ((a.ns + 63) / 64) * COL_CHUNKS;
+  if (b < nmin) { row_col_min_kernel_body(a.C, a.n, a.ns, a.ldt, a.rmin, a.rcnt, a.pmin, a.pcnt, b); return; }
+  b -= nmin;
+  palette_minima_kernel_body(a.ys, a.ns, a.yp, a.n, a.prmin, a.prcnt, a.pcmin, a.pccnt, b);
+}
+// [stage 2 of the REMD column minima + branch (block 0) | palette means + branch (block 1) | the symmetrised self-similarity
+// gradient matrix, four rows per 1024-thread block]: all three read only what step_losses_stats_kernel wrote.
+struct SelectArgs {
+  const float *pmin, *pcnt; int n, ldc; float *cmin, *ccnt; const float* rowmin; int rows, col_is_x; float* loss_out; int* sel;
+  int swapped;
+};
+__global__ __launch_bounds__(1024) void step_losses_select_sym_kernel(SelectArgs r, SelectArgs p, SelfsimSymArgs y) {
+  __shared__ float red[16];
+  if (blockIdx.x < 2) {
+    const SelectArgs& a = blockIdx.x == 0 ? r : p;
+    col_min_final_select_kernel_body(a.pmin, a.pcnt, a.n, a.ldc, a.cmin, a.ccnt, a.rowmin, a.rows, a.col_is_x, a.loss_out,
+                                     a.sel, a.swapped, red);
+    return;
+  }
+  const int g = (int)threadIdx.x >> 8;
+  selfsim_sym_body(y, ((int)blockIdx.x - 2) * 4 + g, (int)threadIdx.x & 255, red + 4 * g, blockIdx.x == 2);
 }
 
 // The same assembly for dist_metrics 'l2' / 'both' (losses.py:18-28): M = l2 or cosine + l2; S holds the l2 part with the sign
@@ -1096,8 +1207,9 @@ int strotss_selfsim_fwd_bwd(const float* pred, const float* content, int n, int 
   hipLaunchKernelGGL(selfsim_rowstat_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, n, ldc, 1.0f / (float)n, s.sx, s.sy,
                      s.tt, s.lossrow);
   const bool bx3 = cost_x3();
-  hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, s.tt, s.rp, n, ldc, ldc,
-                     1.0f / (float)n, s.Mq, s.qdot, bx3 ? s.mp : (__bf16*)nullptr, s.lossrow, 1.0f / (float)n, loss_out);
+  hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st,
+                     SelfsimSymArgs{s.Dx, s.Dy, s.sx, s.sy, s.tt, s.rp, n, ldc, ldc, 1.0f / (float)n, s.Mq, s.qdot,
+                                    bx3 ? s.mp : (__bf16*)nullptr, s.lossrow, 1.0f / (float)n, loss_out});
   if (bx3)
     hipLaunchKernelGGL(center_x3_kernel, dim3(ld / 32, ldc / 32), dim3(256), 0, st, pred, n, ldc, ld, (const float*)nullptr,
                        (__bf16*)nullptr, s.xt);
@@ -1475,28 +1587,27 @@ int strotss_step_losses_fwd_bwd(const float* pred, const float* content, int n, 
   CHK(st_loss_forward_group_x3(m.Pt, m.rows, ld, style_cov, m.Tp, 1.0f / (float)n, m.partial, &n_partial,
                                s.xp, s.rp, n, s.xc - s.xp, s.rc - s.rp, s.Dx, ldc, s.Dy - s.Dx,
                                style_panels, style_inv_norm, ns, r.C, r.ldt, st));
-  // ---- self-similarity statistics | moment loss scalars + mean-gradient signs: one launch
-  hipLaunchKernelGGL(rowstat_finalize_kernel, dim3(n + 1), dim3(256), 0, st, s.Dx, s.Dy, n, ldc, 1.0f / (float)n, s.sx, s.sy,
-                     s.tt, s.lossrow, m.partial, n_partial, style_mean, m.mean, d, ld, m.sgn, loss_moment);
-  hipLaunchKernelGGL(selfsim_sym_kernel, dim3(n), dim3(256), 0, st, s.Dx, s.Dy, s.sx, s.sy, s.tt, s.rp, n, ldc, ldc,
-                     1.0f / (float)n, s.Mq, s.qdot, s.mp, s.lossrow, 1.0f / (float)n, loss_content);
+  // ---- every statistic of the forward products: self-similarity rows | moment scalars + mean-gradient signs | REMD minima |
+  // palette minima (run_strotss.py:37-39, on the YUV rows the prologue made) -- one launch
+  const int ldt = r.ldt;
+  StepStatsArgs sa{s.Dx, s.Dy, n, ldc, 1.0f / (float)n, s.sx, s.sy, s.tt, s.lossrow,
+                   m.partial, n_partial, style_mean, m.mean, d, ld, m.sgn, loss_moment,
+                   r.C, ns, ldt, r.cmin, r.ccnt, r.pmin, r.pcnt,
+                   pl.ys, pl.yp, pl.rmin, pl.rcnt, pl.cmin, pl.ccnt};
+  hipLaunchKernelGGL(step_losses_stats_kernel, dim3((unsigned)(n + 1 + n + cdiv(ns, 64) * COL_CHUNKS + ns + n)), dim3(256), 0, st, sa);
+  // ---- the two branch selections (+ stage 2 of the REMD column minima) | the self-similarity gradient matrix: one launch
+  hipLaunchKernelGGL(step_losses_select_sym_kernel, dim3((unsigned)(2 + cdiv(n, 4))), dim3(1024), 0, st,
+                     SelectArgs{r.pmin, r.pcnt, ns, ldt, r.rmin, r.rcnt, r.cmin, n, 1, loss_remd, r.sel, 0},
+                     SelectArgs{nullptr, nullptr, n, 0, pl.cmin, pl.ccnt, pl.rmin, ns, 0, loss_palette, pl.sel, 0},
+                     SelfsimSymArgs{s.Dx, s.Dy, s.sx, s.sy, s.tt, s.rp, n, ldc, ldc, 1.0f / (float)n, s.Mq, s.qdot, s.mp,
+                                    s.lossrow, 1.0f / (float)n, loss_content});
   LAUNCH_OK();
   CHK(st_selfsim_bwd_x3(s.mp, ldc, s.xt, pred, s.rp, s.qdot, n, ld, g_content, gpred, st));
   CHK(st_moment_bwd_x3(m.Pc, n, ld, m.Tp, g_moment * 2.0f / ((float)n * (float)d * (float)d), m.sgn,
                        g_moment / ((float)d * (float)n), gpred, st));
-  // ---- relaxed EMD on the cost matrix the grouped launch left in r.C: minima, branch, sparse backward
-  const int ldt = r.ldt;
-  hipLaunchKernelGGL(row_col_min_kernel, dim3(n + cdiv(ns, 64) * COL_CHUNKS), dim3(256), 0, st, r.C, n, ns, ldt, r.cmin,
-                     r.ccnt, r.pmin, r.pcnt);
-  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, r.pmin, r.pcnt, ns, ldt, r.rmin, r.rcnt,
-                     r.cmin, n, 1, loss_remd, r.sel, 0);
+  // ---- relaxed EMD and palette: sparse backward kernels
   hipLaunchKernelGGL(remd_cos_bwd_kernel, dim3(n), dim3(256), 0, st, r.C, ldt, style, style_inv_norm, ns, pred, s.rp, n,
                      ld, r.rmin, r.rcnt, r.cmin, r.ccnt, r.sel, g_remd, gpred);
-  // ---- palette term (run_strotss.py:37-39) on the YUV rows the prologue made: minima, branch, backward
-  hipLaunchKernelGGL(palette_minima_kernel, dim3(ns + n), dim3(256), 0, st, pl.ys, ns, pl.yp, n, pl.rmin, pl.rcnt, pl.cmin,
-                     pl.ccnt);
-  hipLaunchKernelGGL(col_min_final_select_kernel, dim3(1), dim3(1024), 0, st, (const float*)nullptr, (const float*)nullptr,
-                     n, 0, pl.cmin, pl.ccnt, pl.rmin, ns, 0, loss_palette, pl.sel, 0);
   hipLaunchKernelGGL(palette_bwd_kernel, dim3(n), dim3(64), 0, st, pl.ys, ns, pl.yp, n, pl.rmin, pl.rcnt, pl.cmin, pl.ccnt,
                      pl.sel, g_palette, gpred, ld, 1);
   ST_LAUNCH_RET();

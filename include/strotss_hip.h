@@ -152,7 +152,10 @@ int strotss_conv3x3_winograd_pack(const float* u_prk, int rows, int k, float* u_
  * mask comes from them and act_in is not read (same result bit for bit: 4 bytes per tile and channel instead of 64).
  * pool_out (may be NULL): also writes strotss_maxpool2_fwd(out) = the (h/2, w/2, cout) input of the next block --
  * from the registers of the fused kernel's epilogue where that kernel runs, by a pooling launch otherwise;
- * pool_code (may be NULL, needs pool_out): the argmax codes of that pooling, see strotss_maxpool2_fwd. */
+ * pool_code (may be NULL, needs pool_out): the argmax codes of that pooling, see strotss_maxpool2_fwd.
+ * accumulate (dgrad, tile_m == 4 with act_in or relu_bits): gin += the masked data-gradient instead of gin = (round 4, ABI 7:
+ * the taps of a tapped layer may be scattered into a zeroed gin before the backward pass -- one scatter launch per step --
+ * when every producer of such a gradient adds, like strotss_conv3x3_dgrad and strotss_maxpool2_bwd). */
 int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const float* u_pok,
                                  const float* u_packed, const void* u_x3, const float* bias,
                                  int cout, int tile_m, float* out,
@@ -160,7 +163,7 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
                                  void* workspace, size_t workspace_bytes, void* stream);
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
                                    const float* u_packed, const void* u_x3, int cin, int tile_m,
-                                   const float* act_in, const unsigned int* relu_bits, float* gin,
+                                   const float* act_in, const unsigned int* relu_bits, float* gin, int accumulate,
                                    void* workspace, size_t workspace_bytes, void* stream);
 /* Which kernels strotss_conv3x3_winograd_fwd / _dgrad run for a layer shape (the routing is a size policy with
  * environment switches, read once per process): what bench.py names in its roofline.  has_packed / has_x3: whether the

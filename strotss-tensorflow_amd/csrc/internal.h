@@ -25,7 +25,7 @@ bool st_winograd43_fused_enabled(int h, int w, int cout);
 int st_winograd43_pack(const float* u_prk, int rows, int k, float* u_packed, hipStream_t st);
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                         const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code,
-                        const unsigned* bits_in, unsigned* bits_out, hipStream_t st);
+                        const unsigned* bits_in, unsigned* bits_out, hipStream_t st, int accumulate = 0);
 int st_maxpool2_fwd(const float* in, int h, int w, int c, float* out, unsigned char* code, hipStream_t st);
 
 // f32 GEMM cores on the bf16 MFMA (mfma_x3.h): operands as "x3 panels" (3 * rows * K bf16 per batch entry)

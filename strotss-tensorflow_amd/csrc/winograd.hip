@@ -228,8 +228,10 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
                                                              const float* __restrict__ mask, int relu,
                                                              float* __restrict__ out, int c4_shift, size_t Tstride,
                                                              const u32x4* __restrict__ bits_in, u32x4* __restrict__ bits_out,
-                                                             f32x4* __restrict__ pool, unsigned* __restrict__ pool_code) {
+                                                             f32x4* __restrict__ pool, unsigned* __restrict__ pool_code,
+                                                             int accumulate) {
   // Tstride: tiles per position plane of Mw (>= TH * TW)
+  // accumulate (data-gradient): out += instead of out = (the layer's taps were scattered into `out` before the backward pass)
   // bits_in / bits_out: sign words of the tile grid (include/strotss_hip.h: relu_bits), one per (tile, channel); with
   // bits_in the mask comes from them (16 bytes per thread instead of 16 x 16 bytes of activations)
   // pool (forward): also the 2x2/2 max-pool of the result and (pool_code) its argmax codes, exactly as maxpool2_fwd_kernel
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void winograd43_out_kernel(const float* __rest
           v[0] = k[0] > 0.f ? v[0] : 0.f; v[1] = k[1] > 0.f ? v[1] : 0.f;
           v[2] = k[2] > 0.f ? v[2] : 0.f; v[3] = k[3] > 0.f ? v[3] : 0.f;
         }
-        dst[o] = v;
+        dst[o] = accumulate ? dst[o] + v : v;
       }
       if (pool) {
         if ((r & 1) == 0) {
@@ -365,12 +367,13 @@ static int g_wino_stages = 7;
 static int winograd43_run(const float* in, int h, int w, int cin, const float* U, const float* Upacked,
                           const void* Ux3, const float* bias, int cout, const float* mask, int relu, float* out,
                           float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
-                          hipStream_t st, const unsigned* bits_in = nullptr, unsigned* bits_out = nullptr) {
+                          hipStream_t st, const unsigned* bits_in = nullptr, unsigned* bits_out = nullptr, int accumulate = 0) {
   // 256 output channels and enough tiles for the bf16x3 GEMMs: the three-kernel form wins (1024-px step 5.102 -> 5.039 ms,
   // three alternating runs each); STROTSS_X3_MIN_COUT (default 256) moves the border
   const bool prefer_x3 = Ux3 && cin % 32 == 0 && winograd43_prefers_x3(h, w, cout);
   if (!prefer_x3 && Upacked && cin % 32 == 0 && st_winograd43_fused_enabled(h, w, cout))      // everything on chip
-    return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, bits_in, bits_out, st);
+    return st_winograd43_fused(in, h, w, cin, Upacked, bias, cout, mask, relu, out, pool_out, pool_code, bits_in, bits_out, st,
+                               accumulate);
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const size_t T = (size_t)TH * TW;
   const bool x3 = Ux3 && cin % 32 == 0 && x3_enabled(T, cout);
@@ -403,7 +406,7 @@ static int winograd43_run(const float* in, int h, int w, int cin, const float* U
                      Mw, h, w, cout / 4, TH, TW, bias, mask, relu, out, log2_or_minus1(cout / 4), Tstride,
                      reinterpret_cast<const u32x4*>(bits_in), reinterpret_cast<u32x4*>(bits_out),
                      reinterpret_cast<f32x4*>(out_pools ? pool_out : nullptr),
-                     reinterpret_cast<unsigned*>(out_pools ? pool_code : nullptr));
+                     reinterpret_cast<unsigned*>(out_pools ? pool_code : nullptr), accumulate);
   if (pool_out && !out_pools) return st_maxpool2_fwd(out, h, w, cout, pool_out, pool_code, st);
   ST_LAUNCH_RET();
 }
@@ -525,15 +528,16 @@ int strotss_conv3x3_winograd_fwd(const float* in, int h, int w, int cin, const f
 
 int strotss_conv3x3_winograd_dgrad(const float* gout, int h, int w, int cout, const float* u_pik,
                                    const float* u_packed, const void* u_x3, int cin, int tile_m,
-                                   const float* act_in, const unsigned int* relu_bits, float* gin,
+                                   const float* act_in, const unsigned int* relu_bits, float* gin, int accumulate,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(gout && u_pik && gin && workspace && h > 0 && w > 0, STROTSS_EINVAL);
   ST_CHECK_ARG(!relu_bits || tile_m == 4, STROTSS_EINVAL);
+  ST_CHECK_ARG(!accumulate || (tile_m == 4 && (act_in || relu_bits)), STROTSS_EINVAL);
   ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
   ST_CHECK_ARG(tile_m == 2 || tile_m == 4, STROTSS_EINVAL);
   if (tile_m == 4)
     return winograd43_run(gout, h, w, cout, u_pik, u_packed, u_x3, nullptr, cin, act_in, 0, gin, nullptr, nullptr, workspace,
-                          workspace_bytes, (hipStream_t)stream, relu_bits, nullptr);
+                          workspace_bytes, (hipStream_t)stream, relu_bits, nullptr, accumulate);
   return winograd_run(gout, h, w, cout, u_pik, nullptr, cin, act_in, 0, gin, workspace, workspace_bytes,
                       (hipStream_t)stream);
 }

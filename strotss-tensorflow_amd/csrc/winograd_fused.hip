@@ -93,14 +93,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct ItemRef { int goff[F_NLOAD]; unsigned okm; int g; };
 
 // in: (H, W, K) NHWC, K % 32 == 0; U: fragment-major (36, Cout, K) weights; out / mask: (H, W, Cout), Cout % 32 == 0.
-// !MASK: out = relu ? max(Y + bias, 0) : Y + bias;  MASK: out = mask > 0 ? Y : 0.
+// !MASK: out = relu ? max(Y + bias, 0) : Y + bias;  MASK: out = mask > 0 ? Y : 0;  ACC (with MASK): out += that (the taps of
+// the layer were scattered into `out` before the backward pass: "pre-scatter", nn/model.py).
 // Work item = (region r of 16x32 output pixels, row-major) x (group g of 32 couts): item = r * NG + g.  The grid is
 // persistent; workgroup b walks the items of its XCD's contiguous range, so the NG groups of a region (same input
 // patch) run on neighbouring CUs of one XCD at the same time and share its L2.
 // The 36 products on the bf16 MFMA with the operands split exactly in registers (round 2: 353 us against 338 us for
 // block1_conv2 forward, the splits' vector instructions take the place of the shorter MFMAs) and a pre-split-planes
 // variant live in tools/experiments/ with their ablation tool; DESIGN.md 4 has the measurements.
-template <bool MASK>
+template <bool MASK, bool ACC = false>
 __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __restrict__ in, int H, int W, int K,
                                                                 const float* __restrict__ U, int Cout,
                                                                 const float* __restrict__ bias,
@@ -415,10 +416,21 @@ __global__ __launch_bounds__(F_NT) void winograd43_fused_kernel(const float* __r
             keep[1] |= (mk[r][c][1] > 0.f ? 1u : 0u) << (4 * r + c);
           }
       }
+      f32x2 old[ACC ? 4 : 1][ACC ? 4 : 1];            // ACC: what the output holds, loaded (clamped) before the first store
+      if constexpr (ACC) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const bool ok = tile_in && yb + r < H && xb + c < W;
+            old[r][c] = *reinterpret_cast<const f32x2*>(op + (ok ? (r * W + c) * Cout : 0));
+          }
+      }
       auto outv = [&](int r, int c) {
         f32x2 v;
         v[0] = ((keep[0] >> (4 * r + c)) & 1u) ? fmaxf(Y[0][r][c], lo) : 0.f;
         v[1] = ((keep[1] >> (4 * r + c)) & 1u) ? fmaxf(Y[1][r][c], lo) : 0.f;
+        if constexpr (ACC) { v[0] += old[r][c][0]; v[1] += old[r][c][1]; }
         return v;
       };
       if (full) {
@@ -524,8 +536,9 @@ bool st_winograd43_fused_enabled(int h, int w, int cout) {
 
 int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, const float* bias, int cout,
                         const float* mask, int relu, float* out, float* pool_out, unsigned char* pool_code,
-                        const unsigned* bits_in, unsigned* bits_out, hipStream_t st) {
+                        const unsigned* bits_in, unsigned* bits_out, hipStream_t st, int accumulate) {
   if (cin % 32 != 0 || cout % 32 != 0) return STROTSS_EALIGN;
+  if (accumulate && !(mask || bits_in)) return STROTSS_EINVAL;       // only the data-gradient form adds to its output
   if ((size_t)h * w * cin >= ((size_t)1 << 30) || (size_t)h * w * cout >= ((size_t)1 << 30)) return STROTSS_EALIGN;
   const int TH = (h + 3) / 4, TW = (w + 3) / 4;
   const int RH = (TH + F_TR - 1) / F_TR, RW = (TW + F_TC - 1) / F_TC;
@@ -540,9 +553,11 @@ int st_winograd43_fused(const float* in, int h, int w, int cin, const float* U, 
   }
   int grid = cus;                                  // persistent: one 147 KB-LDS workgroup per CU, a multiple of 8
   while (grid > 8 && grid / 2 >= nitems) grid /= 2;
-#define LAUNCH_FUSED(M) hipLaunchKernelGGL((winograd43_fused_kernel<M>), dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, \
-                                           cin, U, cout, bias, mask, relu, out, pool_out, pool_code, RW, NG, nitems, bits_in, bits_out)
-  if (mask || bits_in) LAUNCH_FUSED(true); else LAUNCH_FUSED(false);
+#define LAUNCH_FUSED(...) hipLaunchKernelGGL((winograd43_fused_kernel<__VA_ARGS__>), dim3((unsigned)grid), dim3(F_NT), 0, st, in, h, w, \
+                                             cin, U, cout, bias, mask, relu, out, pool_out, pool_code, RW, NG, nitems, bits_in, bits_out)
+  if (accumulate) LAUNCH_FUSED(true, true);
+  else if (mask || bits_in) LAUNCH_FUSED(true);
+  else LAUNCH_FUSED(false);
 #undef LAUNCH_FUSED
   ST_LAUNCH_RET();
 }

@@ -259,7 +259,7 @@ def conv3x3_winograd_fwd(x, u_pok, bias, out=None, pool_out=None, pool_code=None
     return out
 
 
-def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None, relu_bits=None):
+def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None, relu_bits=None, accumulate=False):
     """relu_bits (F(4x4) only): the sign words of the layer's input activation; the ReLU mask then comes from them instead of
     act_in (same result, 1/16 of the bytes)."""
     require(gout, "conv grad"); h, w, cout = hwc(gout)
@@ -270,7 +270,8 @@ def conv3x3_winograd_dgrad(gout, u_pik, cin, act_in=None, out=None, relu_bits=No
     ws, nb = _wino_ws(h, w, cout, cin, m, gout.device)
     check(_hip.lib().strotss_conv3x3_winograd_dgrad(ptr(gout), h, w, cout, ptr(u_pik), ptr(winograd_packed(u_pik)),
                                                     ptr(winograd_x3(u_pik, h, w)), cin,
-                                                    m, ptr(act_in), ptr(relu_bits), ptr(out), ptr(ws), nb, stream_ptr()),
+                                                    m, ptr(act_in), ptr(relu_bits), ptr(out), int(accumulate), ptr(ws), nb,
+                                                    stream_ptr()),
           "conv3x3_winograd_dgrad")
     return out
 

@@ -282,12 +282,16 @@ class VGGTrunk:
                         if self.wtile[si] == 4 or params.layers[si]["cin"] == 3:
                             a = self.acts[si]
                             self.relu_bits[si] = _ops.relu_bits_buffer(int(a.shape[1]), int(a.shape[2]), int(a.shape[3]), dev)
-            # Small maps ("pre-scatter" backward): when EVERY tapped layer's gradient is produced by a kernel that can
-            # add to its output (the split-K direct data-gradient, the pooling backward, the first layer's pixel
-            # gradient), the taps of all maps are scattered in ONE launch into zeroed buffers before the backward pass
-            # and the producers accumulate -- 10 launches less per step at the 64 / 128 px scales.  The tapped layers'
-            # gradient buffers are then slices of one allocation (one fill).
-            self.prescatter = (halo is None and self._can_prescatter()
+            # "Pre-scatter" backward: when EVERY tapped layer's gradient is produced by a kernel that can add to its
+            # output (the split-K direct data-gradient, the F(4x4,3x3) data-gradients since ABI 7, the pooling backward,
+            # the first layer's pixel gradient), the taps of all maps are scattered in ONE launch into zeroed buffers
+            # before the backward pass and the producers accumulate -- 9 launches less per step.  It costs ONE fill of
+            # every tapped gradient buffer plus the producers' extra read of their output, so it pays only where the maps
+            # are tiny: measured (alternating runs on one box) 256 px 1.188 against 1.185 ms per step interleaved, 512 px
+            # 1.904 against 1.860 (65 / 262 MB of fill) -- hence up to 160 x 160 pixels, the 64 / 128-px scales, by default
+            # (STROTSS_PRESCATTER_MAX_PIXELS).  The tapped layers' gradient buffers are then slices of one allocation.
+            max_px = int(os.environ.get("STROTSS_PRESCATTER_MAX_PIXELS", str(160 * 160)))
+            self.prescatter = (halo is None and h * w <= max_px and self._can_prescatter()
                                and os.environ.get("STROTSS_PRESCATTER", "1") != "0")
             if self.prescatter:
                 sizes = [a.numel() if i in set(self.taps) else 0 for i, a in enumerate(self.acts)]
@@ -313,6 +317,8 @@ class VGGTrunk:
             if kind == 'conv' and si in tapped:           # layer li's data-gradient writes the tapped grads[si]
                 L = self.p.layers[li]
                 a = self.acts[li]
+                if self.wtile[li] == 4:
+                    continue                              # winograd_dgrad(accumulate=1): any F(4x4,3x3) route
                 if self.wtile[li] != 0 or not _ops.conv3x3_direct_splits(int(a.shape[1]), int(a.shape[2]), L["cout"], L["cin"]):
                     return False
         return n - 1 in tapped                            # (the deepest layer is scattered into a zeroed buffer anyway)
@@ -391,7 +397,10 @@ class VGGTrunk:
                     dgrad = _ops.conv3x3_winograd_dgrad if wino else _ops.conv3x3_dgrad
                     wts = L["u_bwd"][self.wtile[li]] if wino else L["w_bwd"]
                     if kind == 'conv':
-                        if pre and si in tapped:
+                        if pre and si in tapped and wino:
+                            dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si],
+                                  relu_bits=self.relu_bits[si], accumulate=True)
+                        elif pre and si in tapped:
                             dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si], accumulate=True)
                         elif wino and self.relu_bits[si] is not None:
                             dgrad(self.grads[li], wts, L["cin"], act_in=self.acts[si], out=self.grads[si],

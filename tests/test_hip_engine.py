@@ -268,9 +268,24 @@ def test_prescatter_backward_equals_the_interleaved_one():
     det.forward_backward([i0])
     for a, b in zip(pre, det.gvars):
         assert float((a - b).norm() / b.norm()) < 1e-5
-    # a big map keeps the interleaved scatter (Winograd data-gradients overwrite their output)
-    S = _setup(256, 256, 256, seed=5)
-    assert not S["eng"].trunk.prescatter
+    # 256 px: the tapped gradients come from F(4x4,3x3) data-gradients (fused kernel and three-kernel form), which can add to
+    # their output since ABI 7; the policy keeps the interleaved scatter there (the fill of the tapped buffers costs what the
+    # nine launches save: nn/model.py), STROTSS_PRESCATTER_MAX_PIXELS moves the border -- same gradient either way
+    assert not _setup(256, 256, 256, seed=5)["eng"].trunk.prescatter
+    os.environ["STROTSS_PRESCATTER_MAX_PIXELS"] = str(256 * 256)
+    try:
+        S = _setup(256, 256, 256, seed=5)
+    finally:
+        del os.environ["STROTSS_PRESCATTER_MAX_PIXELS"]
+    eng = S["eng"]
+    assert eng.trunk.prescatter
+    i0 = torch.from_numpy(S["idx_sets"][0][0]).to(DEV)
+    eng.forward_backward([i0])
+    pre = [g.clone() for g in eng.gvars]
+    eng.trunk.prescatter = False
+    eng.forward_backward([i0])
+    for a, b in zip(pre, eng.gvars):
+        assert float((a - b).norm() / b.norm()) < 1e-5
 
 
 # ------------------------------------------------------------------ operator surface (autograd)

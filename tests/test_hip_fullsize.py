@@ -304,3 +304,29 @@ def test_relu_sign_words_fullsize(cfg):
     a = _ops.conv3x3_winograd_dgrad(gy, u_b, cin, act_in=x)
     b = _ops.conv3x3_winograd_dgrad(gy, u_b, cin, relu_bits=xbits)
     assert torch.equal(a, b)
+    # accumulate (ABI 7, the pre-scatter backward): gin += the same masked gradient -- ONE f32 addition per element
+    pre = _rand(1, hw, hw, cin, seed=9)
+    for kw in ({"act_in": x}, {"relu_bits": xbits}):
+        c = pre.clone()
+        _ops.conv3x3_winograd_dgrad(gy, u_b, cin, out=c, accumulate=True, **kw)
+        assert torch.equal(c, pre + a), kw.keys()
+
+
+@pytest.mark.parametrize("cfg", [(64, 256, 256), (32, 512, 512), (62, 128, 256)])
+def test_winograd_dgrad_accumulate_small_maps(cfg):
+    """The same on the maps of the 256 / 512-px scales, where the F(4x4,3x3) data-gradient runs as three kernels with f32 GEMMs
+    (and a ragged 62 x 62 map): out += the masked gradient, bit for bit one addition."""
+    from nn import _ops
+    hw, cin, cout = cfg
+    g = torch.Generator().manual_seed(hw + cin)
+    wt = torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    x = _rand(1, hw, hw, cin, seed=3, relu=True)
+    u_b = _ops.winograd_weights(wt.flip(0, 1).permute(2, 3, 0, 1).contiguous().to(DEV), 4, DEV)
+    gy = _rand(1, hw, hw, cout, seed=4)
+    a = _ops.conv3x3_winograd_dgrad(gy, u_b, cin, act_in=x)
+    pre = _rand(1, hw, hw, cin, seed=5)
+    c = pre.clone()
+    _ops.conv3x3_winograd_dgrad(gy, u_b, cin, act_in=x, out=c, accumulate=True)
+    assert torch.equal(c, pre + a)
+    with pytest.raises(Exception):                       # no mask source: only the masked (tapped-layer) form accumulates
+        _ops.conv3x3_winograd_dgrad(gy, u_b, cin, out=c, accumulate=True)

@@ -225,7 +225,10 @@ int strotss_hypercol_gather2(const strotss_maps_t* maps_a, const strotss_maps_t*
 /* Adjoint (bilinear only): gmap_k[pixel, c] += w * gfeat[s, off_k + c] * (relu_mask ? map_k>0 : 1)
  * for the maps k in [map_begin, map_end) only (the backward pass of the trunk needs the taps'
  * contributions one layer at a time); gmap[k] may be NULL outside that range.
- * relu_mask_from: maps with index >= relu_mask_from are post-ReLU activations (mask applied). */
+ * relu_mask_from: maps with index >= relu_mask_from are post-ReLU activations (mask applied).
+ * Float atomics, except for maps of at most 64 pixels (the 4 x 4 / 8 x 8 maps of the 64 / 128-px scales, where hundreds of
+ * samples share an address): there one workgroup owns a (pixel, channel chunk) and adds its samples in sample order --
+ * no atomics, the same bits on every run for those maps (STROTSS_SCATTER_DENSE=0: atomics everywhere). */
 int strotss_hypercol_scatter(const strotss_maps_t* maps, const float* idx, int n,
                              const float* gfeat, int ld, int relu_mask_from, int map_begin,
                              int map_end, void* stream);

@@ -410,11 +410,95 @@ __global__ __launch_bounds__(256) void hypercol_gather2_kernel(strotss_maps_t ma
     gather_row(mb, idx, b - n, bilinear, out_b, ld, dtotal_b);
   }
 }
+// Tiny maps (at most SCATTER_DENSE_MAX_PIX pixels: the 4 x 4 and 8 x 8 maps of the 64 / 128-px scales): 4096 taps land on 16-64
+// pixels, i.e. 64-256 atomic adds per address, and the memory side serialises them (22 us for the 4 x 4 x 512 map against
+// 11 us for the same adds spread over a 16 x 16 one).  There ONE workgroup owns a (pixel, 64-channel chunk): it lists the
+// samples with a tap on its pixel (weights of coinciding taps summed), in sample order, its four waves add the listed rows of
+// gfeat with four loads in flight, and the four partial sums are combined in a fixed order and added with a plain
+// read-modify-write: no atomics, bitwise reproducible for these maps.  b: block index within map k, off: first column of map k.
+#define SCATTER_DENSE_MAX_PIX 64
+__device__ __forceinline__ void scatter_dense_block(const strotss_maps_t& m, const float* __restrict__ idx, int n,
+                                                    const float* __restrict__ gfeat, int ld, bool masked, int k, int off, int b) {
+  __shared__ int li[1024];
+  __shared__ float lw[1024];
+  __shared__ int cnts[4];
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = m.c[k], nchunk = (c + 63) >> 6;
+  const int p = b / nchunk, q = b - p * nchunk;
+  const int s0 = m.sample_range ? m.sample_range[0] : 0, s1 = m.sample_range ? min(n, m.sample_range[1]) : n;
+  const int ch = q * 64 + lane;
+  const bool in = ch < c;
+  const float* g = gfeat + off + (in ? ch : c - 1);
+  float acc = 0.f;
+  for (int base = s0; base < s1; base += 1024) {
+    float w4[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = base + 4 * tid + u;
+      float w = 0.f;
+      if (s < s1) {
+        const SampleTap t = sample_tap(m, k, idx[2 * s], idx[2 * s + 1], 1);
+        w = (t.ia == p ? t.wa : 0.f) + (t.ib == p ? t.wb : 0.f) + (t.ic == p ? t.wc : 0.f) + (t.id == p ? t.wd : 0.f);
+      }
+      w4[u] = w;
+      cnt += w != 0.f;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    __syncthreads();                                  // (the previous chunk's list has been read)
+    if (lane == 63) cnts[wave] = incl;
+    __syncthreads();
+    int at = incl - cnt, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+      at += wv < wave ? cnts[wv] : 0;
+      total += cnts[wv];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (w4[u] != 0.f) { li[at] = base + 4 * tid + u; lw[at] = w4[u]; ++at; }
+    __syncthreads();
+    int e = wave;
+    for (; e + 12 < total; e += 16) {                 // this wave's entries e, e + 4, e + 8, e + 12: four rows in flight
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = g[(size_t)li[e + 4 * u] * ld];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += lw[e + 4 * u] * v[u];
+    }
+    for (; e < total; e += 4) acc += lw[e] * g[(size_t)li[e] * ld];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && in) {
+    const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const size_t o = (size_t)p * c + ch;
+    if (tot != 0.f && (!masked || m.map[k][o] > 0.f)) m.gmap[k][o] += tot;
+  }
+}
 __global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m, const float* __restrict__ idx,
                                                                const float* __restrict__ gfeat, int ld,
                                                                int relu_mask_from, int map_begin,
-                                                               int map_end) {
-  const int s = blockIdx.x;
+                                                               int map_end, int n, unsigned dense_mask, int dense_blocks) {
+  if ((int)blockIdx.x < dense_blocks) {               // the tiny maps' (pixel, channel chunk) blocks come first
+    int b = (int)blockIdx.x, off = 0;
+    for (int k = 0; k < map_end; ++k) {
+      if ((dense_mask >> k) & 1u) {
+        const int nb = (m.rows[k] > 0 ? m.rows[k] : m.h[k]) * m.w[k] * ((m.c[k] + 63) >> 6);
+        if (b < nb) { scatter_dense_block(m, idx, n, gfeat, ld, k >= relu_mask_from, k, off, b); return; }
+        b -= nb;
+      }
+      off += m.c[k];
+    }
+    return;
+  }
+  const int s = (int)blockIdx.x - dense_blocks;
   if (m.sample_range && (s < m.sample_range[0] || s >= m.sample_range[1])) return;
   const float gx = idx[2 * s], gy = idx[2 * s + 1];
   const float* g = gfeat + (size_t)s * ld;
@@ -426,7 +510,7 @@ __global__ __launch_bounds__(256) void hypercol_scatter_kernel(strotss_maps_t m,
     const int c = m.c[k], nchunk = (c + 63) >> 6;
     const int q0 = (wave - chunk) & 3;
     chunk += nchunk;
-    if (k < map_begin || q0 >= nchunk) { off += c; continue; }
+    if (k < map_begin || q0 >= nchunk || ((dense_mask >> k) & 1u)) { off += c; continue; }
     const SampleTap t = sample_tap(m, k, gx, gy, 1);
     const float* act = m.map[k];
     float* dst = m.gmap[k];
@@ -745,8 +829,21 @@ int strotss_hypercol_scatter(const strotss_maps_t* maps, const float* idx, int n
     d += maps->c[k];
   }
   ST_CHECK_ARG(ld >= d, STROTSS_EINVAL);
-  hipLaunchKernelGGL(hypercol_scatter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, *maps, idx, gfeat,
-                     ld, relu_mask_from, map_begin, map_end);
+  // maps of at most SCATTER_DENSE_MAX_PIX pixels: one workgroup per (pixel, channel chunk) instead of contended atomics
+  // (STROTSS_SCATTER_DENSE: 0 = never, 1 or unset = up to SCATTER_DENSE_MAX_PIX pixels, n > 1 = up to n pixels)
+  static const int dense_pix = [] {
+    const char* e = getenv("STROTSS_SCATTER_DENSE");
+    const int v = e ? atoi(e) : 1;
+    return v == 1 ? SCATTER_DENSE_MAX_PIX : v;
+  }();
+  unsigned dense_mask = 0;
+  int dense_blocks = 0;
+  for (int k = map_begin; k < map_end; ++k) {
+    const int pix = (maps->rows[k] > 0 ? maps->rows[k] : maps->h[k]) * maps->w[k];
+    if (pix <= dense_pix) { dense_mask |= 1u << k; dense_blocks += pix * ((maps->c[k] + 63) / 64); }
+  }
+  hipLaunchKernelGGL(hypercol_scatter_kernel, dim3(n + dense_blocks), dim3(256), 0, (hipStream_t)stream, *maps, idx, gfeat,
+                     ld, relu_mask_from, map_begin, map_end, n, dense_mask, dense_blocks);
   ST_LAUNCH_RET();
 }
 

@@ -328,6 +328,42 @@ def test_hypercol_gather_and_scatter(ops, hw):
         assert np.abs(a.cpu().numpy() - ref_g).max() < 1e-5 * max(1.0, np.abs(ref_g).max()), k
 
 
+def test_tiny_maps_take_the_dense_tap_adjoint(ops):
+    """Maps of at most 64 pixels (csrc/image.hip: scatter_dense_block -- the 4 x 4 and 8 x 8 maps of the 64 / 128-px scales, where
+    1024 samples put 64-256 atomic adds on every address): one workgroup per (pixel, channel chunk), no atomics.  Same adjoint
+    as the float64 autograd of the oracle's gather, the same bits on every run for those maps, wide (> 64 channels, ragged
+    130) and 1024 samples (hundreds of entries per pixel list) included."""
+    g = torch.Generator().manual_seed(77)
+    h, w = 32, 32
+    shapes = [(h, w, 3), (h, w, 8), (h // 2, w // 2, 16), (h // 4, w // 4, 130), (h // 8, w // 8, 256), (h // 16, w // 16, 70)]
+    maps = [torch.relu(torch.randn(1, *s, generator=g, dtype=torch.float64)) + (0.5 if i == 0 else 0.0) for i, s in enumerate(shapes)]
+    idx = O.make_indices(h, w, True, 1024, np.random.default_rng(6))
+    idx[0] = (h - 1, w - 1); idx[1] = (0, 0)
+    n = len(idx)
+    dmaps = [dev(m) for m in maps]
+    d = sum(m.shape[-1] for m in maps)
+    leaves = [m.clone().requires_grad_(True) for m in maps]
+    gf = torch.randn(n, d, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    (O.sample_features(leaves, idx, True) * gf).sum().backward()
+    gbuf = torch.zeros(ops.pad32(n), ops.pad32(d), device="cuda"); gbuf[:n, :d] = dev(gf)
+    runs = []
+    for split in (False, True, False):
+        gm = [torch.zeros_like(m) for m in dmaps]
+        if split:                                        # map ranges, as the interleaved backward launches them
+            ops.hypercol_scatter(dmaps, gm, dev(idx), gbuf, relu_mask_from=1, map_begin=4, map_end=len(maps))
+            ops.hypercol_scatter(dmaps, gm, dev(idx), gbuf, relu_mask_from=1, map_begin=0, map_end=4)
+        else:
+            ops.hypercol_scatter(dmaps, gm, dev(idx), gbuf, relu_mask_from=1)
+        torch.cuda.synchronize()
+        runs.append(gm)
+    for k, (leaf, m) in enumerate(zip(leaves, maps)):
+        ref_g = leaf.grad.numpy() * ((m.numpy() > 0) if k >= 1 else 1.0)
+        for r in runs:
+            assert np.abs(r[k].cpu().numpy() - ref_g).max() < 1e-5 * max(1.0, np.abs(ref_g).max()), k
+        if m.shape[1] * m.shape[2] <= 64:                # the dense path: no atomics -> the same bits, whatever the launch split
+            assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
+
+
 def test_atomic_tap_adjoint_equals_the_sorted_one_bit_for_bit_on_exact_sums(ops):
     """One launch of the float-atomic tap adjoint against one of the sorted one on inputs whose sums are EXACT in f32 (integer
     sample coordinates -> tap weights are multiples of 1/64, integer feature gradients): whatever order the atomics land in,

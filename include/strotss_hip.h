@@ -111,6 +111,18 @@ int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float
 /* accumulate != 0: gin += the (masked) data gradient instead of being overwritten -- the buffer then already holds the
  * hypercolumn taps' contributions of this layer (scattered in one launch for all maps before the backward pass);
  * supported by the split-K form only (strotss_conv3x3_workspace_bytes(h, w, cout, cin) > 0), STROTSS_EINVAL otherwise. */
+/* Block ends at the split-K scales (ABI 8): the finish kernel of a split-K layer also does the 2x2/2 max-pool that follows it
+ * (forward: out AND pool_out = strotss_maxpool2_fwd(out) with its argmax codes pool_code, may be NULL) or precedes it
+ * (data-gradient of a layer whose input came from the pool: gin_full(full_h, full_w, cin) (+)= strotss_maxpool2_bwd's result
+ * from the codes, full_h / 2 == h, full_w / 2 == w; the pooled gradient itself is never stored) -- one launch less per block
+ * and direction, bit for bit the two-launch results.  Split-K layers only (strotss_conv3x3_workspace_bytes(...) > 0 and that
+ * workspace given): STROTSS_EINVAL otherwise. */
+int strotss_conv3x3_relu_pool_fwd(const float* in, int h, int w, int cin, const float* w_tok, const float* bias, int cout,
+                                  float* out, float* pool_out, unsigned char* pool_code, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+int strotss_conv3x3_dgrad_unpool(const float* gout, int h, int w, int cout, const float* w_tik, int cin,
+                                 const unsigned char* pool_code, float* gin_full, int full_h, int full_w, int accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 int strotss_conv3x3_dgrad(const float* gout, int h, int w, int cout, const float* w_tik, int cin,
                           const float* act_in, float* gin, int accumulate, void* workspace, size_t workspace_bytes,
                           void* stream);

@@ -292,6 +292,118 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const f32x4* __
     out[e] = accumulate ? out[e] + v : v;
   }
 }
+// The same finish for a layer that is followed by the 2x2/2 max-pool (block ends): thread = one pooled element (4 channels) --
+// it finishes the four pixels of its window (partial tiles added in split order, + bias, ReLU: the bits of the plain finish),
+// stores them, and writes their maximum and its argmax code exactly as maxpool2_fwd_kernel would from `out`.  An odd last
+// row / column lies in no window: finished and stored, not pooled.  One launch less per block at the split-K scales.
+__global__ __launch_bounds__(256) void conv_splitk_finish_pool_kernel(const f32x4* __restrict__ part, int nsplit, size_t total4,
+                                                                      int H, int W, int C4, const f32x4* __restrict__ bias,
+                                                                      f32x4* __restrict__ out, f32x4* __restrict__ pool,
+                                                                      unsigned* __restrict__ code) {
+  const int Ho = H >> 1, Wo = W >> 1, Wx = Wo + (W & 1), rows = Ho + (H & 1);
+  const int row_elems = Wx * C4;
+  for (int oy = blockIdx.y; oy < rows; oy += gridDim.y)
+    for (int er = blockIdx.x * 256 + threadIdx.x; er < row_elems; er += gridDim.x * 256) {
+      const int ox = er / C4, c = er - ox * C4;
+      size_t o[4];
+      bool ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                                // q = (dy << 1) | dx
+        const int y = 2 * oy + (q >> 1), x = 2 * ox + (q & 1);
+        ok[q] = y < H && x < W;
+        o[q] = ok[q] ? ((size_t)y * W + x) * C4 + c : (size_t)c;   // clamped: loaded unconditionally, stored if ok
+      }
+      f32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = part[o[q]];
+      int sp = 1;
+      for (; sp + 4 <= nsplit; sp += 4) {                          // 4 pixels x 4 partial tiles in flight, split order per pixel
+        f32x4 p4[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) p4[q][u] = part[(size_t)(sp + u) * total4 + o[q]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v[q] + p4[q][u];
+      }
+      for (; sp < nsplit; ++sp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] + part[(size_t)sp * total4 + o[q]];
+      const f32x4 b = bias[c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = v[q] + b;
+        v[q][0] = fmaxf(v[q][0], 0.f); v[q][1] = fmaxf(v[q][1], 0.f); v[q][2] = fmaxf(v[q][2], 0.f); v[q][3] = fmaxf(v[q][3], 0.f);
+        if (ok[q]) out[o[q]] = v[q];
+      }
+      if (oy < Ho && ox < Wo) {
+        f32x4 m;
+        unsigned packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          m[k] = fmaxf(fmaxf(v[0][k], v[1][k]), fmaxf(v[2][k], v[3][k]));
+          int best = 0;
+          float bv = v[0][k];
+#pragma unroll
+          for (int q = 1; q < 4; ++q)
+            if (v[q][k] > bv) { bv = v[q][k]; best = q; }
+          packed |= (unsigned)(bv > 0.f ? best : 4) << (8 * k);
+        }
+        const size_t e = ((size_t)oy * Wo + ox) * C4 + c;
+        pool[e] = m;
+        if (code) code[e] = packed;
+      }
+    }
+}
+// The finish of a data-gradient whose layer's input came from the 2x2/2 max-pool, written THROUGH the pool's adjoint: thread =
+// one pooled element, v = its partial tiles added in split order (what the plain finish would store as the pooled gradient),
+// then the 2 x 2 window of the (H, W) gradient of the layer in front of the pool from the argmax codes, as
+// maxpool2_bwd_code_kernel does -- the pooled gradient is never stored, one launch less per block.
+__global__ __launch_bounds__(256) void conv_splitk_finish_unpool_kernel(const f32x4* __restrict__ part, int nsplit, size_t total4,
+                                                                        int H, int W, int C4, const unsigned* __restrict__ code,
+                                                                        f32x4* __restrict__ gin, int accumulate) {
+  const int Ho = H >> 1, Wo = W >> 1, Wx = Wo + (W & 1);
+  const int row_elems = Wx * C4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int oy = blockIdx.y; oy < Ho + (H & 1); oy += gridDim.y) {
+    const bool pooled_row = oy < Ho;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < row_elems; e += gridDim.x * 256) {
+      const int ox = e / C4, c = e - ox * C4;
+      const bool pooled = pooled_row && ox < Wo;
+      f32x4 r[4] = {z, z, z, z};
+      if (pooled) {
+        const size_t po = ((size_t)oy * Wo + ox) * C4 + c;
+        const unsigned cd = code[po];
+        f32x4 go = part[po];
+        int sp = 1;
+        for (; sp + 8 <= nsplit; sp += 8) {
+          f32x4 p8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) p8[u] = part[(size_t)(sp + u) * total4 + po];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) go = go + p8[u];
+        }
+        for (; sp < nsplit; ++sp) go = go + part[(size_t)sp * total4 + po];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned me = (cd >> (8 * k)) & 0xffu;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r[q][k] = me == (unsigned)q ? go[k] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int y = 2 * oy + (q >> 1), x = 2 * ox + (q & 1);
+        if (y < H && x < W) {
+          const size_t o = ((size_t)y * W + x) * C4 + c;
+          gin[o] = accumulate ? gin[o] + r[q] : r[q];
+        }
+      }
+    }
+  }
+}
 // number of K splits for a (h, w, cin, cout) layer, 0 = one-pass kernel: only when the layer is at most 128 tiles of 64 x 64
 static int conv_splits(int H, int W, int Cin, int Cout) {
   static int on = -1;
@@ -348,9 +460,16 @@ int launch_conv(const float* in, int H, int W, int Cin, const float* wt, const f
   ST_LAUNCH_RET();
 }
 
+// what the finish of a split-K layer also does at a block end (the pooling launch it replaces): forward -- the pooled copy
+// and its argmax codes; data-gradient -- the result goes through the pool's adjoint into the (2h.., 2w..) gradient in front
+struct FinishPool {
+  float* pool = nullptr; unsigned char* code = nullptr;                               // forward
+  const unsigned char* ucode = nullptr; float* ugin = nullptr; int uH = 0, uW = 0;    // data-gradient
+};
+
 int conv_dispatch(const float* in, int H, int W, int Cin, const float* wt, const float* bias, int Cout,
                   const float* mask, float* out, int relu, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0,
-                  int accumulate = 0) {
+                  int accumulate = 0, const FinishPool* fp = nullptr) {
   const int64_t M = (int64_t)H * W;
   const int nsplit = conv_splits(H, W, Cin, Cout);
   if (nsplit && workspace && workspace_bytes >= (size_t)nsplit * M * Cout * sizeof(float)) {
@@ -359,12 +478,26 @@ int conv_dispatch(const float* in, int H, int W, int Cin, const float* wt, const
     hipLaunchKernelGGL((conv3x3_mfma_splitk_kernel<Cfg>), dim3(tiles * nsplit), dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, Cout,
                        nsplit, (float*)workspace);
     const size_t total4 = (size_t)M * Cout / 4;
+    if (fp && fp->pool) {
+      const int C4 = Cout / 4, rows = (H >> 1) + (H & 1), row_elems = ((W >> 1) + (W & 1)) * C4;
+      hipLaunchKernelGGL(conv_splitk_finish_pool_kernel, dim3((unsigned)min(64, cdiv(row_elems, 256)), (unsigned)rows), dim3(256), 0, s,
+                         (const f32x4*)workspace, nsplit, total4, H, W, C4, (const f32x4*)bias, (f32x4*)out, (f32x4*)fp->pool,
+                         (unsigned*)fp->code);
+      ST_LAUNCH_RET();
+    }
+    if (fp && fp->ugin) {
+      const int C4 = Cout / 4, rows = (fp->uH >> 1) + (fp->uH & 1), row_elems = ((fp->uW >> 1) + (fp->uW & 1)) * C4;
+      hipLaunchKernelGGL(conv_splitk_finish_unpool_kernel, dim3((unsigned)min(64, cdiv(row_elems, 256)), (unsigned)rows), dim3(256), 0,
+                         s, (const f32x4*)workspace, nsplit, total4, fp->uH, fp->uW, C4, (const unsigned*)fp->ucode,
+                         (f32x4*)fp->ugin, accumulate);
+      ST_LAUNCH_RET();
+    }
     hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)min((size_t)2048, (total4 + 255) / 256)), dim3(256), 0, s,
                        (const f32x4*)workspace, nsplit, total4, Cout / 4, (const f32x4*)bias, (const f32x4*)mask, relu,
                        (f32x4*)out, accumulate);
     ST_LAUNCH_RET();
   }
-  if (accumulate) return STROTSS_EINVAL;              // only the split-K form adds to its output
+  if (accumulate || fp) return STROTSS_EINVAL;        // only the split-K form adds to its output / pools in its finish
   if (Cout % 128 == 0 && cdiv(M, 128) * (Cout / 128) >= 512)
     return launch_conv<128, 128>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s);
   if (cdiv(M, 128) * (Cout / 64) >= 512)
@@ -852,6 +985,28 @@ int strotss_conv3x3_dgrad(const float* gout, int h, int w, int cout, const float
   // the transposed convolution is a convolution with K = cout and N = cin
   return conv_dispatch(gout, h, w, cout, w_tik, nullptr, cin, act_in, gin, 0, (hipStream_t)stream, workspace, workspace_bytes,
                        accumulate);
+}
+
+int strotss_conv3x3_relu_pool_fwd(const float* in, int h, int w, int cin, const float* w_tok, const float* bias, int cout,
+                                  float* out, float* pool_out, unsigned char* pool_code, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  ST_CHECK_ARG(in && w_tok && bias && out && pool_out && workspace && h > 1 && w > 1, STROTSS_EINVAL);
+  ST_CHECK_ARG(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 64 == 0, STROTSS_EALIGN);
+  FinishPool fp;
+  fp.pool = pool_out; fp.code = pool_code;
+  return conv_dispatch(in, h, w, cin, w_tok, bias, cout, nullptr, out, 1, (hipStream_t)stream, workspace, workspace_bytes, 0, &fp);
+}
+
+int strotss_conv3x3_dgrad_unpool(const float* gout, int h, int w, int cout, const float* w_tik, int cin,
+                                 const unsigned char* pool_code, float* gin_full, int full_h, int full_w, int accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(gout && w_tik && pool_code && gin_full && workspace && h > 0 && w > 0, STROTSS_EINVAL);
+  ST_CHECK_ARG((full_h >> 1) == h && (full_w >> 1) == w, STROTSS_EINVAL);
+  ST_CHECK_ARG(cout > 0 && cout % 32 == 0 && cin > 0 && cin % 64 == 0, STROTSS_EALIGN);
+  FinishPool fp;
+  fp.ucode = pool_code; fp.ugin = gin_full; fp.uH = full_h; fp.uW = full_w;
+  return conv_dispatch(gout, h, w, cout, w_tik, nullptr, cin, nullptr, nullptr, 0, (hipStream_t)stream, workspace, workspace_bytes,
+                       accumulate, &fp);
 }
 
 int strotss_conv3x3_c3_dgrad(const float* gout, int h, int w, int cout, const float* w_tic,

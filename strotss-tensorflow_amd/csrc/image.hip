@@ -707,7 +707,7 @@ int maps_ok(const strotss_maps_t* m) {
 
 extern "C" {
 
-int strotss_abi_version(void) { return 7; }
+int strotss_abi_version(void) { return 8; }
 const char* strotss_build_info(void) { return "libstrotss_hip gfx950 fp32-mfma " __DATE__ " " __TIME__; }
 
 int strotss_resize_bilinear(const float* in, int ih, int iw, int c, float* out, int oh, int ow, float alpha,

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STROTSS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libstrotss_hip.so")
 
 MAX_MAPS, MAX_DIVS, MAX_TENSORS = 12, 8, 8
-ABI_VERSION = 7          # must equal strotss_abi_version() of the loaded library (argument lists change with it)
+ABI_VERSION = 8          # must equal strotss_abi_version() of the loaded library (argument lists change with it)
 
 
 class StrotssHipError(RuntimeError):
@@ -71,6 +71,8 @@ SIGNATURES = {
     "strotss_conv3x3_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "strotss_conv3x3_relu_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "strotss_conv3x3_dgrad": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
+    "strotss_conv3x3_relu_pool_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "strotss_conv3x3_dgrad_unpool": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "strotss_conv3x3_c3_dgrad": (_I, [_P, _I, _I, _I, _P, C.POINTER(_F), _P, _I, _P]),
     "strotss_conv3x3_winograd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "strotss_conv3x3_winograd_weights": (_I, [_P, _I, _I, _I, _P, _P]),

@@ -122,13 +122,18 @@ def conv3x3_c3_fwd(img, w_kio, bias, out=None, mean=None, std=None, relu_bits_ou
     return out
 
 
-def conv3x3_relu_fwd(x, w_tok, bias, out=None):
+def conv3x3_relu_fwd(x, w_tok, bias, out=None, pool_out=None, pool_code=None):
+    """pool_out (split-K layers only, conv3x3_direct_splits): the finish kernel also writes maxpool2_fwd(out) (+ pool_code)."""
     require(x, "conv input"); h, w, cin = hwc(x)
     cout = bias.numel()
     if out is None:
         out = torch.empty((1, h, w, cout), dtype=torch.float32, device=x.device)
     nb = _hip.lib().strotss_conv3x3_workspace_bytes(h, w, cin, cout)
     ws = workspaces.get("conv_splitk", nb, x.device) if nb else None
+    if pool_out is not None:
+        check(_hip.lib().strotss_conv3x3_relu_pool_fwd(ptr(x), h, w, cin, ptr(w_tok), ptr(bias), cout, ptr(out), ptr(pool_out),
+                                                       ptr(pool_code), ptr(ws), nb, stream_ptr()), "conv3x3_relu_pool_fwd")
+        return out
     check(_hip.lib().strotss_conv3x3_relu_fwd(ptr(x), h, w, cin, ptr(w_tok), ptr(bias), cout, ptr(out), ptr(ws), nb,
                                               stream_ptr()), "conv3x3_relu_fwd")
     return out
@@ -148,6 +153,19 @@ def conv3x3_dgrad(gout, w_tik, cin, act_in=None, out=None, accumulate=False):
     check(_hip.lib().strotss_conv3x3_dgrad(ptr(gout), h, w, cout, ptr(w_tik), cin, ptr(act_in), ptr(out), int(accumulate),
                                            ptr(ws), nb, stream_ptr()), "conv3x3_dgrad")
     return out
+
+
+def conv3x3_dgrad_unpool(gout, w_tik, cin, pool_code, out_full, accumulate=False):
+    """Data gradient of a split-K layer whose input came from the 2x2/2 max-pool, written through the pool's adjoint:
+    out_full (1, H, W, cin) (+)= maxpool2_bwd(code=pool_code, conv^T(gout)); the pooled gradient is never stored."""
+    require(gout, "conv grad"); h, w, cout = hwc(gout)
+    require(out_full, "gradient in front of the pool"); fh, fw, fc = hwc(out_full)
+    assert fc == cin and fh // 2 == h and fw // 2 == w, (out_full.shape, gout.shape, cin)
+    nb = _hip.lib().strotss_conv3x3_workspace_bytes(h, w, cout, cin)
+    ws = workspaces.get("conv_splitk", nb, gout.device) if nb else None
+    check(_hip.lib().strotss_conv3x3_dgrad_unpool(ptr(gout), h, w, cout, ptr(w_tik), cin, ptr(pool_code), ptr(out_full), fh, fw,
+                                                  int(accumulate), ptr(ws), nb, stream_ptr()), "conv3x3_dgrad_unpool")
+    return out_full
 
 
 def conv3x3_c3_dgrad(gout, w_tic, gimg=None, accumulate=False, std=None):

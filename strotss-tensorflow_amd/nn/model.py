@@ -306,6 +306,8 @@ class VGGTrunk:
             self.gpools = [torch.empty_like(p) for p in self.pools]
             self.gimg = self._gimg_in_flat if self.prescatter else torch.empty((1, h, w, 3), dtype=torch.float32, device=dev)
         self.img = None
+        # block ends on split-K layers: the max-pool (and its adjoint) inside the layer's finish kernel (ABI 8)
+        self._pool_in_finish = halo is None and os.environ.get("STROTSS_POOL_IN_FINISH", "1") != "0"
 
     def _can_prescatter(self) -> bool:
         tapped = set(self.taps)
@@ -353,7 +355,16 @@ class VGGTrunk:
                     _ops.conv3x3_winograd_fwd(x, L["u_fwd"][self.wtile[li]], L["bias"], out=self.acts[li],
                                               pool_out=pool_out, pool_code=pool_code, relu_bits_out=self.relu_bits[li])
                 else:
-                    _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=self.acts[li])
+                    nxt = self.plan[si + 1] if si + 1 < len(self.plan) else None
+                    a = self.acts[li]
+                    if (self._pool_in_finish and nxt is not None and nxt[0] == 'pool' and nxt[2] == li
+                            and _ops.conv3x3_direct_splits(int(a.shape[1]), int(a.shape[2]), L["cin"], L["cout"])):
+                        # split-K layer at a block end: its finish kernel pools as well
+                        _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=a, pool_out=self.pools[nxt[1]],
+                                              pool_code=self.pool_codes[nxt[1]] if self.with_grad else None)
+                        pooled.add(nxt[1])
+                    else:
+                        _ops.conv3x3_relu_fwd(x, L["w_fwd"], L["bias"], out=a)
                 if self.halo is not None:     # (the pooling launch that may follow then reads right rows only)
                     self.halo.refresh(self.acts[li], self.layer_level[li])
         return [self.acts[i] for i in self.taps]
@@ -378,11 +389,14 @@ class VGGTrunk:
             self.grads[last].zero_()
             scatter(last)
         # walk the plan backwards; grads[li] always holds the ReLU-masked gradient of layer li's output
+        unpooled = set()                # pools whose adjoint the finish kernel of the layer behind them has already applied
+        pool_src = {s_[1]: s_[2] for s_ in self.plan if s_[0] == 'pool'}
         for step in reversed(self.plan):
             if step[0] == 'pool':
                 _, pi, src_layer = step
-                _ops.maxpool2_bwd(self.acts[src_layer], self.gpools[pi], out=self.grads[src_layer],
-                                  code=self.pool_codes[pi], accumulate=pre and src_layer in tapped)
+                if pi not in unpooled:
+                    _ops.maxpool2_bwd(self.acts[src_layer], self.gpools[pi], out=self.grads[src_layer],
+                                      code=self.pool_codes[pi], accumulate=pre and src_layer in tapped)
                 if src_layer in tapped:
                     scatter(src_layer)
             else:
@@ -412,7 +426,15 @@ class VGGTrunk:
                         if self.halo is not None:
                             self.halo.refresh(self.grads[si], self.layer_level[si])
                     else:
-                        dgrad(self.grads[li], wts, L["cin"], act_in=None, out=self.gpools[si])
+                        g = self.grads[li]
+                        if (self._pool_in_finish and not wino
+                                and _ops.conv3x3_direct_splits(int(g.shape[1]), int(g.shape[2]), L["cout"], L["cin"])):
+                            src_layer = pool_src[si]
+                            _ops.conv3x3_dgrad_unpool(g, wts, L["cin"], self.pool_codes[si], self.grads[src_layer],
+                                                      accumulate=pre and src_layer in tapped)
+                            unpooled.add(si)
+                        else:
+                            dgrad(g, wts, L["cin"], act_in=None, out=self.gpools[si])
                         if self.halo is not None:
                             self.halo.refresh(self.gpools[si], self.pool_level[si])
         return self.gimg

@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in strotss_hip.h but not exported"
     assert sorted(_hip.SIGNATURES) == declared_symbols()
     typed = _hip.load_library()
-    assert typed.strotss_abi_version() == _hip.ABI_VERSION == 7
+    assert typed.strotss_abi_version() == _hip.ABI_VERSION == 8
     assert b"gfx950" in typed.strotss_build_info()
 
 

@@ -165,6 +165,43 @@ def test_conv_generic_fwd_and_dgrad(ops, cfg):
                 ops.conv3x3_dgrad(dev(gy), dev(w_tik), cin, act_in=dev(x), out=dev(base).clone(), accumulate=True)
 
 
+@pytest.mark.parametrize("cfg", [(16, 24, 64, 64), (9, 7, 64, 128), (8, 8, 512, 512), (4, 4, 256, 512), (5, 12, 128, 64)])
+def test_split_k_finish_pools_at_block_ends(ops, cfg):
+    """ABI 8: a split-K layer's finish kernel also does the 2x2/2 max-pool behind it (forward) or in front of it
+    (data-gradient of the next block's first layer): bit for bit the two-launch results -- activations, pooled copy, argmax
+    codes; the gradient in front of the pool, overwritten or added to -- odd rows / columns (outside every window) included."""
+    h, w, cin, cout = cfg
+    assert ops.conv3x3_direct_splits(h, w, cin, cout)
+    g = torch.Generator().manual_seed(h * 31 + w + cin)
+    x = dev(torch.relu(torch.randn(1, h, w, cin, generator=g)))
+    wt = torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = dev(torch.randn(cout, generator=g) * 0.1)
+    w_tok = dev(wt.permute(0, 1, 3, 2).reshape(9, cout, cin).contiguous())
+    y = ops.conv3x3_relu_fwd(x, w_tok, b)
+    code = torch.empty((1, h // 2, w // 2, cout), dtype=torch.uint8, device="cuda")
+    p = ops.maxpool2_fwd(y, code=code)
+    y2 = torch.full_like(y, -3.0)
+    p2 = torch.full_like(p, -3.0)
+    code2 = torch.full_like(code, 9)
+    ops.conv3x3_relu_fwd(x, w_tok, b, out=y2, pool_out=p2, pool_code=code2)
+    assert torch.equal(y, y2) and torch.equal(p, p2) and torch.equal(code, code2)
+    # the next block's first layer: (h/2, w/2, cout) -> cout2 channels; its data-gradient through the pool's adjoint
+    ph, pw, c2 = h // 2, w // 2, 64
+    if not ops.conv3x3_direct_splits(ph, pw, c2, cout):
+        return
+    wt2 = torch.randn(3, 3, cout, c2, generator=g) * (2.0 / (9 * cout)) ** 0.5
+    w_tik = dev(wt2.flip(0, 1).reshape(9, cout, c2).contiguous())
+    gy = dev(torch.randn(1, ph, pw, c2, generator=g))
+    gpool = ops.conv3x3_dgrad(gy, w_tik, cout)
+    want = ops.maxpool2_bwd(y, gpool, code=code)
+    got = ops.conv3x3_dgrad_unpool(gy, w_tik, cout, code, torch.full_like(y, 7.0))
+    assert torch.equal(got, want)
+    base = dev(torch.randn(y.shape, generator=g))
+    want = ops.maxpool2_bwd(y, gpool, out=base.clone(), code=code, accumulate=True)
+    got = ops.conv3x3_dgrad_unpool(gy, w_tik, cout, code, base.clone(), accumulate=True)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("cfg", [(16, 24, 128, 256), (9, 7, 256, 256), (5, 3, 512, 512), (33, 20, 64, 64),
                                  (1, 1, 128, 128), (2, 4, 256, 512), (70, 37, 128, 64), (16, 32, 64, 128), (19, 45, 32, 64)])
 @pytest.mark.parametrize("tile_m", [2, 4])

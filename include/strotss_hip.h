@@ -109,8 +109,7 @@ int strotss_conv3x3_relu_fwd(const float* in, int h, int w, int cin, const float
  *   flipped kernel, tap' = (2-dy)*3+(2-dx).  act_in = the layer's (post-ReLU) input or NULL
  *   when the input came from a max-pool. */
 /* accumulate != 0: gin += the (masked) data gradient instead of being overwritten -- the buffer then already holds the
- * hypercolumn taps' contributions of this layer (scattered in one launch for all maps before the backward pass);
- * supported by the split-K form only (strotss_conv3x3_workspace_bytes(h, w, cout, cin) > 0), STROTSS_EINVAL otherwise. */
+ * hypercolumn taps' contributions of this layer (scattered in one launch for all maps before the backward pass). */
 /* Block ends at the split-K scales (ABI 8): the finish kernel of a split-K layer also does the 2x2/2 max-pool that follows it
  * (forward: out AND pool_out = strotss_maxpool2_fwd(out) with its argmax codes pool_code, may be NULL) or precedes it
  * (data-gradient of a layer whose input came from the pool: gin_full(full_h, full_w, cin) (+)= strotss_maxpool2_bwd's result

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_pipe_kernel(const float*
                                                                     int Cin, const float* __restrict__ wt,
                                                                     const float* __restrict__ bias, int Cout,
                                                                     const float* __restrict__ mask,
-                                                                    float* __restrict__ out, int relu) {
+                                                                    float* __restrict__ out, int relu, int accumulate) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   const int HW = H * W;
   const unsigned gx = Cout / Cfg::BN;                       // 1-D launch, XCD-aware tile order (N-tile fastest)
@@ -211,6 +211,17 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_pipe_kernel(const float*
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) mv[reg] = 1.f;
       }
+      float ov[16];
+      if (accumulate) {  // (data-gradient into a buffer that already holds the layer's scattered taps: loads first, as the mask's)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int p = min(m0 + map.row(im, reg), HW - 1);
+          ov[reg] = out[(size_t)p * Cout + co];
+        }
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) ov[reg] = 0.f;
+      }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int p = m0 + map.row(im, reg);
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_mfma_pipe_kernel(const float*
           float v = acc[im][in_][reg] + b;
           if (relu) v = fmaxf(v, 0.f);
           v = (mv[reg] > 0.f) ? v : 0.f;
-          out[(size_t)p * Cout + co] = v;
+          out[(size_t)p * Cout + co] = accumulate ? ov[reg] + v : v;
         }
       }
     }
@@ -436,9 +447,10 @@ static int conv_waves() {
 
 template <int BM, int BN>
 int launch_conv(const float* in, int H, int W, int Cin, const float* wt, const float* bias, int Cout,
-                const float* mask, float* out, int relu, hipStream_t s) {
+                const float* mask, float* out, int relu, hipStream_t s, int accumulate) {
   dim3 grid(Cout / BN, cdiv((int64_t)H * W, BM));
   if (conv_variant() == 1) {
+    if (accumulate) return STROTSS_EINVAL;             // (the two-barrier A/B kernel overwrites)
     hipLaunchKernelGGL((conv3x3_mfma_kernel<BM, BN>), grid, dim3(256), 0, s, in, H, W, Cin, wt, bias, Cout,
                        mask, out, relu);
     ST_LAUNCH_RET();
@@ -448,14 +460,14 @@ int launch_conv(const float* in, int H, int W, int Cin, const float* wt, const f
     if (conv_waves() == 8) {
       using Cfg = PipeCfg<BM, BN, (BN == 128 ? 2 : 4), (BN == 128 ? 4 : 2)>;
       hipLaunchKernelGGL((conv3x3_mfma_pipe_kernel<Cfg>), grid1, dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, bias, Cout,
-                         mask, out, relu);
+                         mask, out, relu, accumulate);
       ST_LAUNCH_RET();
     }
   }
   {
     using Cfg = PipeCfg<BM, BN, 2, 2>;
     hipLaunchKernelGGL((conv3x3_mfma_pipe_kernel<Cfg>), grid1, dim3(Cfg::NT), 0, s, in, H, W, Cin, wt, bias, Cout,
-                       mask, out, relu);
+                       mask, out, relu, accumulate);
   }
   ST_LAUNCH_RET();
 }
@@ -497,12 +509,12 @@ int conv_dispatch(const float* in, int H, int W, int Cin, const float* wt, const
                        (f32x4*)out, accumulate);
     ST_LAUNCH_RET();
   }
-  if (accumulate || fp) return STROTSS_EINVAL;        // only the split-K form adds to its output / pools in its finish
+  if (fp) return STROTSS_EINVAL;                      // only the split-K form pools in its finish
   if (Cout % 128 == 0 && cdiv(M, 128) * (Cout / 128) >= 512)
-    return launch_conv<128, 128>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s);
+    return launch_conv<128, 128>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s, accumulate);
   if (cdiv(M, 128) * (Cout / 64) >= 512)
-    return launch_conv<128, 64>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s);
-  return launch_conv<64, 64>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s);
+    return launch_conv<128, 64>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s, accumulate);
+  return launch_conv<64, 64>(in, H, W, Cin, wt, bias, Cout, mask, out, relu, s, accumulate);
 }
 
 // ---------------------------------------------------------------- first layer (Cin = 3)

@@ -321,7 +321,7 @@ class VGGTrunk:
                 a = self.acts[li]
                 if self.wtile[li] == 4:
                     continue                              # winograd_dgrad(accumulate=1): any F(4x4,3x3) route
-                if self.wtile[li] != 0 or not _ops.conv3x3_direct_splits(int(a.shape[1]), int(a.shape[2]), L["cout"], L["cin"]):
+                if self.wtile[li] != 0:                   # (F(2x2,3x3) overwrites; the direct kernels add, split-K or not)
                     return False
         return n - 1 in tapped                            # (the deepest layer is scattered into a zeroed buffer anyway)
 

@@ -154,15 +154,10 @@ def test_conv_generic_fwd_and_dgrad(ops, cfg):
         assert rel_err(got, xin.grad.numpy()) < 3e-6
         got = ops.conv3x3_dgrad(dev(gy), dev(w_tik), cin, act_in=dev(x)).cpu().numpy()
         assert rel_err(got, (xin.grad * (x > 0)).numpy()) < 3e-6
-        # accumulate (pre-scatter backward): the split-K form adds the masked gradient to its output, the big-map
-        # form refuses instead of silently overwriting
+        # accumulate (pre-scatter backward): split-K and one-pass form alike add the masked gradient to their output
         base = torch.randn(x.shape, generator=g, dtype=torch.float64).float()
-        if ops.conv3x3_direct_splits(h, w, cout, cin):
-            acc = ops.conv3x3_dgrad(dev(gy), dev(w_tik), cin, act_in=dev(x), out=dev(base).clone(), accumulate=True)
-            assert np.array_equal(acc.cpu().numpy(), base.numpy() + got)
-        else:
-            with pytest.raises(RuntimeError):
-                ops.conv3x3_dgrad(dev(gy), dev(w_tik), cin, act_in=dev(x), out=dev(base).clone(), accumulate=True)
+        acc = ops.conv3x3_dgrad(dev(gy), dev(w_tik), cin, act_in=dev(x), out=dev(base).clone(), accumulate=True)
+        assert np.array_equal(acc.cpu().numpy(), base.numpy() + got)
 
 
 @pytest.mark.parametrize("cfg", [(16, 24, 64, 64), (9, 7, 64, 128), (8, 8, 512, 512), (4, 4, 256, 512), (5, 12, 128, 64)])

@@ -251,6 +251,8 @@ def test_prescatter_backward_equals_the_interleaved_one():
     """Small scales (nn/model.py VGGTrunk: every tapped layer's gradient comes from an accumulating producer): all maps'
     taps land in ONE scatter launch before the backward pass.  Same kernels and inputs otherwise -> the pixel gradient
     equals the interleaved form's to summation-order rounding; the deterministic engine (no atomics) must agree too."""
+    if os.environ.get("STROTSS_PRESCATTER") == "0":
+        pytest.skip("the switch under test is off in this run")
     S = _setup(64, 64, 384, seed=5)
     eng = S["eng"]
     assert eng.trunk.prescatter, "64 px: all tapped layers' producers are split-K direct dgrads or pool backwards"
